@@ -1,0 +1,280 @@
+"""ctypes front-end of the CPU oracle (oracle/br_oracle.c).
+
+TEST INFRASTRUCTURE ONLY.  Importers allowed: tests/, __graft_entry__.smoke(),
+bench.py's cpu_baseline leg.  br_amd/ never imports this module.
+
+Mirrors the reference's seams so the parity tests read like the reference's own
+tests: Solid (pcon::solid::Solid as used in src/correct/*/tests), Corrector
+(src/correct/mod.rs:44-108) built per method like build_methods
+(src/lib.rs:141-164), correct_batch = run_correction's per-record body
+(src/lib.rs:42-55).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import Iterable, List, Sequence, Tuple
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libbr_oracle.so")
+
+METHODS = {"one": 0, "two": 1, "graph": 2, "greedy": 3, "gap_size": 4}
+
+
+def build(force: bool = False) -> str:
+    src = os.path.join(_HERE, "br_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "libbr_oracle.so"])
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    L = C.CDLL(build())
+    u8p, u64p, vp = C.POINTER(C.c_uint8), C.POINTER(C.c_uint64), C.c_void_p
+    sig = {
+        "bro_nuc2bit": (C.c_uint64, [C.c_uint8]),
+        "bro_bit2nuc": (C.c_uint8, [C.c_uint64]),
+        "bro_seq2bit": (C.c_uint64, [C.c_char_p, C.c_size_t]),
+        "bro_revcomp": (C.c_uint64, [C.c_uint64, C.c_int]),
+        "bro_canonical": (C.c_uint64, [C.c_uint64, C.c_int]),
+        "bro_hash": (C.c_uint64, [C.c_uint64, C.c_int]),
+        "bro_mask": (C.c_uint64, [C.c_int]),
+        "bro_solid_nbytes": (C.c_uint64, [C.c_int]),
+        "bro_solid_new": (vp, [C.c_int]),
+        "bro_solid_free": (None, [vp]),
+        "bro_solid_k": (C.c_int, [vp]),
+        "bro_solid_bits": (u8p, [vp]),
+        "bro_solid_set": (None, [vp, C.c_uint64, C.c_int]),
+        "bro_solid_get": (C.c_int, [vp, C.c_uint64]),
+        "bro_solid_popcount": (C.c_uint64, [vp]),
+        "bro_solid_set_seq": (None, [vp, C.c_char_p, C.c_size_t]),
+        "bro_solid_from_count": (vp, [C.c_int, vp, C.c_uint8]),
+        "bro_solid_from_bytes": (vp, [C.c_char_p, C.c_size_t]),
+        "bro_solid_wrap": (vp, [C.c_int, vp]),
+        "bro_solid_unwrap": (None, [vp]),
+        "bro_solid_extend": (None, [vp, vp]),
+        "bro_count_nbytes": (C.c_uint64, [C.c_int]),
+        "bro_count_seq": (None, [vp, C.c_int, vp, C.c_size_t]),
+        "bro_hashes_seq": (C.c_size_t, [C.c_int, vp, C.c_size_t, vp]),
+        "bro_corrector_new": (vp, [vp, C.c_int, C.c_int, C.c_int]),
+        "bro_corrector_free": (None, [vp]),
+        "bro_corrector_stats": (None, [vp, u64p]),
+        "bro_alt_nucs": (C.c_int, [vp, C.c_uint64, u64p]),
+        "bro_correct": (vp, [vp, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]),
+        "bro_correct_record": (vp, [C.POINTER(vp), C.c_int, C.c_int, C.c_char_p, C.c_size_t,
+                                    C.POINTER(C.c_size_t)]),
+        "bro_correct_batch": (vp, [C.POINTER(vp), C.c_int, C.c_int, vp, vp, C.c_uint32, vp]),
+        "bro_free": (None, [vp]),
+        "bro_solid_mask": (None, [vp, vp, C.c_size_t, vp]),
+        "bro_bio_global": (C.c_size_t, [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, vp]),
+    }
+    for name, (res, args) in sig.items():
+        f = getattr(L, name)
+        f.restype = res
+        f.argtypes = args
+    _lib = L
+    return L
+
+
+def seq2bit(s: bytes) -> int:
+    return lib().bro_seq2bit(s, len(s))
+
+
+def revcomp(kmer: int, k: int) -> int:
+    return lib().bro_revcomp(kmer, k)
+
+
+def canonical(kmer: int, k: int) -> int:
+    return lib().bro_canonical(kmer, k)
+
+
+def khash(kmer: int, k: int) -> int:
+    return lib().bro_hash(kmer, k)
+
+
+class Solid:
+    """pcon::solid::Solid restated (bitset of canonical k-mers, Lsb0)."""
+
+    def __init__(self, k: int, _h=None, _keep=None):
+        self._L = lib()
+        self._h = _h if _h is not None else self._L.bro_solid_new(k)
+        if not self._h:
+            raise MemoryError("solid alloc failed")
+        self._wrapped = _keep is not None
+        self._keep = _keep
+
+    def __del__(self):
+        try:
+            if self._h:
+                if self._wrapped:
+                    self._L.bro_solid_unwrap(self._h)
+                else:
+                    self._L.bro_solid_free(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    @property
+    def k(self) -> int:
+        return self._L.bro_solid_k(self._h)
+
+    def set(self, kmer: int, val: bool = True) -> None:
+        self._L.bro_solid_set(self._h, kmer, 1 if val else 0)
+
+    def get(self, kmer: int) -> bool:
+        return bool(self._L.bro_solid_get(self._h, kmer))
+
+    def set_seq(self, seq: bytes) -> None:
+        """set every forward k-mer of seq (Tokenizer loop of the reference tests)."""
+        self._L.bro_solid_set_seq(self._h, seq, len(seq))
+
+    def popcount(self) -> int:
+        return self._L.bro_solid_popcount(self._h)
+
+    def bits(self) -> np.ndarray:
+        n = self._L.bro_solid_nbytes(self.k)
+        p = self._L.bro_solid_bits(self._h)
+        return np.ctypeslib.as_array(p, shape=(n,))
+
+    def to_bytes(self) -> bytes:
+        return bytes([self.k]) + self.bits().tobytes()
+
+    @classmethod
+    def from_bytes(cls, buf: bytes) -> "Solid":
+        L = lib()
+        h = L.bro_solid_from_bytes(buf, len(buf))
+        if not h:
+            raise ValueError("bad .solid stream")
+        return cls(buf[0], _h=h)
+
+    @classmethod
+    def from_count(cls, k: int, counts: np.ndarray, abundance: int) -> "Solid":
+        L = lib()
+        counts = np.ascontiguousarray(counts, dtype=np.uint8)
+        assert counts.size == L.bro_count_nbytes(k)
+        h = L.bro_solid_from_count(k, counts.ctypes.data, abundance)
+        return cls(k, _h=h)
+
+    @classmethod
+    def wrap(cls, k: int, bits: np.ndarray) -> "Solid":
+        """zero-copy view over an existing Lsb0 bit array (e.g. a 16 GiB GPU export)."""
+        L = lib()
+        assert bits.dtype == np.uint8 and bits.flags.c_contiguous
+        assert bits.size == L.bro_solid_nbytes(k)
+        h = L.bro_solid_wrap(k, bits.ctypes.data)
+        return cls(k, _h=h, _keep=bits)
+
+    def extend(self, other: "Solid") -> None:
+        self._L.bro_solid_extend(self._h, other._h)
+
+    def mask(self, seq: bytes) -> np.ndarray:
+        n = max(len(seq) - self.k + 1, 0)
+        out = np.zeros((n + 7) // 8, dtype=np.uint8)
+        buf = np.frombuffer(seq, dtype=np.uint8)
+        if n:
+            self._L.bro_solid_mask(self._h, buf.ctypes.data, len(seq), out.ctypes.data)
+        return out
+
+
+def count_reads(k: int, reads: Iterable[bytes]) -> np.ndarray:
+    """pcon Counter<u8>::count_fasta restated: dense u8 table, saturating."""
+    L = lib()
+    counts = np.zeros(L.bro_count_nbytes(k), dtype=np.uint8)
+    for r in reads:
+        b = np.frombuffer(r, dtype=np.uint8)
+        L.bro_count_seq(counts.ctypes.data, k, b.ctypes.data, len(r))
+    return counts
+
+
+def hashes(k: int, read: bytes) -> np.ndarray:
+    L = lib()
+    out = np.zeros(max(len(read) - k + 1, 0), dtype=np.uint64)
+    if out.size:
+        b = np.frombuffer(read, dtype=np.uint8)
+        L.bro_hashes_seq(k, b.ctypes.data, len(read), out.ctypes.data)
+    return out
+
+
+class Corrector:
+    """One corrector of build_methods (src/lib.rs:141-164)."""
+
+    def __init__(self, solid: Solid, method: str, confirm: int = 5, max_search: int = 7):
+        self._L = lib()
+        self.solid = solid
+        self.method = method
+        self._h = self._L.bro_corrector_new(solid._h, METHODS[method], confirm, max_search)
+
+    def __del__(self):
+        try:
+            if self._h:
+                self._L.bro_corrector_free(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def correct(self, seq: bytes) -> bytes:
+        n = C.c_size_t(0)
+        p = self._L.bro_correct(self._h, seq, len(seq), C.byref(n))
+        out = C.string_at(p, n.value)
+        self._L.bro_free(p)
+        return out
+
+    def stats(self) -> dict:
+        a = (C.c_uint64 * 9)()
+        self._L.bro_corrector_stats(self._h, a)
+        names = ["positions", "triggers", "fixes", "fix_i", "fix_s", "fix_d", "rej_alts", "rej_noscen",
+                 "rej_multi"]
+        return dict(zip(names, [int(v) for v in a]))
+
+
+def build_methods(solid: Solid, methods: Sequence[str], confirm: int = 5, max_search: int = 7) -> List[Corrector]:
+    return [Corrector(solid, m, confirm, max_search) for m in methods]
+
+
+def correct_record(methods: Sequence[Corrector], seq: bytes, two_side: bool = False) -> bytes:
+    L = lib()
+    arr = (C.c_void_p * len(methods))(*[m._h for m in methods])
+    n = C.c_size_t(0)
+    p = L.bro_correct_record(arr, len(methods), 1 if two_side else 0, seq, len(seq), C.byref(n))
+    out = C.string_at(p, n.value)
+    L.bro_free(p)
+    return out
+
+
+def correct_batch(methods: Sequence[Corrector], bases: np.ndarray, offsets: np.ndarray,
+                  two_side: bool = False) -> Tuple[np.ndarray, np.ndarray]:
+    """bases: uint8[total]; offsets: uint64[n+1].  Returns (out_bases, out_offsets)."""
+    L = lib()
+    bases = np.ascontiguousarray(bases, dtype=np.uint8)
+    offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+    n = offsets.size - 1
+    arr = (C.c_void_p * len(methods))(*[m._h for m in methods])
+    out_off = np.zeros(n + 1, dtype=np.uint64)
+    p = L.bro_correct_batch(arr, len(methods), 1 if two_side else 0, bases.ctypes.data, offsets.ctypes.data,
+                            n, out_off.ctypes.data)
+    total = int(out_off[-1])
+    out = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(max(total, 1),))[:total].copy()
+    L.bro_free(p)
+    return out, out_off
+
+
+def alt_nucs(solid: Solid, kmer: int) -> List[int]:
+    a = (C.c_uint64 * 4)()
+    n = lib().bro_alt_nucs(solid._h, kmer, a)
+    return [int(a[i]) for i in range(n)]
+
+
+def bio_global(x: bytes, y: bytes) -> str:
+    """rust-bio global alignment ops as a string of M/X/D/I (Match/Subst/Del/Ins)."""
+    ops = np.zeros(len(x) + len(y) + 2, dtype=np.uint8)
+    n = lib().bro_bio_global(x, len(x), y, len(y), ops.ctypes.data)
+    return "".join("MXDI"[int(o)] for o in ops[:n])

@@ -1,0 +1,141 @@
+"""Pins the CPU oracle (oracle/br_oracle.c) against every golden vector the reference's
+own tests hold for the hot path.  CPU only."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+
+def _solid_for(v):
+    s = O.Solid(v["k"])
+    for q in v["set_seqs"]:
+        s.set_seq(q.encode())
+    for q in v["set_kmers"]:
+        s.set(O.seq2bit(q.encode()))
+    return s
+
+
+def test_unit_vectors_count(unit_vectors):
+    vs = unit_vectors["vectors"]
+    active = [v for v in vs if not v["ignored"]]
+    # 9 One + 11 Graph + 7 GapSize + 10 Greedy (3 more #[ignore]d) + 15 Two
+    assert len(active) == 52 and len(vs) == 55
+
+
+def test_corrector_vectors(unit_vectors):
+    for v in unit_vectors["vectors"]:
+        if v["ignored"]:
+            continue
+        s = _solid_for(v)
+        c = O.Corrector(s, v["method"], v["confirm"], v["max_search"])
+        for a, b in v["cases"]:
+            assert c.correct(a.encode()).decode() == b, v["name"]
+
+
+def test_found_alt_kmer(unit_vectors):
+    d = unit_vectors["set"]["found_alt_kmer"]
+    s = O.Solid(d["k"])
+    for q in d["set_kmers"]:
+        s.set(O.seq2bit(q.encode()))
+    assert O.alt_nucs(s, O.seq2bit(d["query"].encode())) == d["alt_nucs"]
+
+
+def test_pcon_set_vectors(unit_vectors):
+    d = unit_vectors["set"]["pcon"]
+    k, seq = d["k"], d["seq"].encode()
+    s = O.Solid(k)
+    s.set_seq(seq)
+    for i in range(len(seq) - k + 1):
+        fwd = O.seq2bit(seq[i:i + k])
+        assert s.get(fwd)                       # forward
+        assert s.get(O.canonical(fwd, k))       # canonical
+        assert s.get(O.revcomp(fwd, k))
+    assert not s.get(d["absent_kmer"])          # absence
+    assert s.k == k
+
+
+def test_codec_conventions():
+    assert [O.lib().bro_nuc2bit(c) for c in b"ACTGactgN"] == [0, 1, 2, 3, 0, 1, 2, 3, 3]
+    assert bytes(O.lib().bro_bit2nuc(b) for b in range(4)) == b"ACTG"
+    assert O.seq2bit(b"ACTG") == 0b00011011
+    k = 5
+    x = O.seq2bit(b"ACTGC")
+    assert O.revcomp(x, k) == O.seq2bit(b"GCAGT")
+    # exactly one of {x, revcomp} has even popcount for odd k
+    for x in range(0, 4 ** k, 7):
+        rc = O.revcomp(x, k)
+        assert (bin(x).count("1") + bin(rc).count("1")) % 2 == 1
+        assert O.canonical(x, k) == O.canonical(rc, k)
+        assert O.khash(x, k) < 2 ** (2 * k - 1)
+
+
+def test_set_build_kat(raw_reads, solid_fixture_bytes, unit_vectors):
+    """tests/data/raw.fasta counted at k=11, solid iff count > 2, must equal the
+    reference's raw.k11.a2.solid bit for bit."""
+    d = unit_vectors["set"]["solid_fixture"]
+    assert solid_fixture_bytes[0] == d["k"] and len(solid_fixture_bytes) == 1 + d["n_bits"] // 8
+    counts = O.count_reads(d["k"], raw_reads)
+    s = O.Solid.from_count(d["k"], counts, d["abundance"])
+    assert s.popcount() == d["set_bits"]
+    assert s.to_bytes() == solid_fixture_bytes
+    # >= instead of > must NOT reproduce it (guards the comparator)
+    s2 = O.Solid.from_count(d["k"], counts, d["abundance"] - 1)
+    assert s2.to_bytes() != solid_fixture_bytes
+
+
+def test_solid_roundtrip_and_extend(solid_fixture_bytes):
+    s = O.Solid.from_bytes(solid_fixture_bytes)
+    assert s.to_bytes() == solid_fixture_bytes
+    t = O.Solid(11)
+    t.extend(s)
+    assert t.to_bytes() == solid_fixture_bytes
+    with pytest.raises(ValueError):
+        O.Solid.from_bytes(solid_fixture_bytes[:-1])
+
+
+def test_one_regression_stats(raw_reads, solid_fixture_bytes):
+    """Event counts of SURVEY P8 / BASELINE.md section 2 (independent python restatement)."""
+    s = O.Solid.from_bytes(solid_fixture_bytes)
+    c = O.Corrector(s, "one", 5, 7)
+    total = changed = 0
+    for r in raw_reads:
+        o = O.correct_record([c], r, two_side=False)
+        total += len(o)
+        changed += o != r
+    st = c.stats()
+    assert st["positions"] == 5035792
+    assert st["triggers"] == 195011
+    assert (st["fixes"], st["fix_d"], st["fix_i"], st["fix_s"]) == (23048, 8371, 7633, 7044)
+    assert (st["rej_alts"], st["rej_noscen"], st["rej_multi"]) == (52394, 119378, 191)
+    assert total == 2520330 and changed == 205
+
+
+def test_batch_equals_record(raw_reads, solid_fixture_bytes):
+    s = O.Solid.from_bytes(solid_fixture_bytes)
+    ms = O.build_methods(s, ["one", "graph"], 5, 7)
+    reads = raw_reads[:8] + [b"", b"ACGT", raw_reads[9][:11]]
+    bases = np.frombuffer(b"".join(reads), dtype=np.uint8)
+    offs = np.zeros(len(reads) + 1, dtype=np.uint64)
+    offs[1:] = np.cumsum([len(r) for r in reads])
+    for two_side in (False, True):
+        ob, oo = O.correct_batch(ms, bases, offs, two_side)
+        for i, r in enumerate(reads):
+            assert ob[int(oo[i]):int(oo[i + 1])].tobytes() == O.correct_record(ms, r, two_side)
+
+
+def test_short_and_edge_reads(solid_fixture_bytes):
+    s = O.Solid.from_bytes(solid_fixture_bytes)
+    for m in O.METHODS:
+        c = O.Corrector(s, m, 5, 7)
+        assert c.correct(b"") == b""
+        assert c.correct(b"ACGTACGTAC") == b"ACGTACGTAC"          # len < k: returned verbatim
+        assert c.correct(b"acgtnACGTNN") == b"acgtnACGTNN"        # len == k: nothing to scan
+
+
+def test_bio_global_basics():
+    assert O.bio_global(b"ACGT", b"ACGT") == "MMMM"
+    assert O.bio_global(b"ACGT", b"AGGT") == "MXMM"
+    ops = O.bio_global(b"ACGTT", b"ACGT")
+    assert ops.count("I") == 1 and ops.count("D") == 0 and len(ops) == 5
+    ops = O.bio_global(b"ACGT", b"ACGTT")
+    assert ops.count("D") == 1 and ops.count("I") == 0
