@@ -1,0 +1,205 @@
+// Diagnostics, device selection and the per-kernel event timers of libbrx.so.
+#include "brx_internal.hpp"
+
+#include <stdio.h>
+#include <string.h>
+#include <map>
+
+namespace brx {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int use_device(int device)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        set_error("no usable HIP device (hipGetDeviceCount: %s); libbrx has no CPU fallback",
+                  e == hipSuccess ? "0 devices" : hipGetErrorString(e));
+        return BRX_ERR_NODEVICE;
+    }
+    if (device < 0 || device >= n) {
+        set_error("device %d out of range (0..%d)", device, n - 1);
+        return BRX_ERR_ARG;
+    }
+    BRX_HIP(hipSetDevice(device));
+    return BRX_OK;
+}
+
+// ---- timers ---------------------------------------------------------------------------------
+struct TimerSlot {
+    std::string name;
+    double total_ms = 0;
+    uint64_t launches = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+};
+
+static std::mutex g_tmu;
+static bool g_prof_on = false;
+static std::vector<TimerSlot> g_slots;
+static std::vector<hipEvent_t> g_pool;
+
+static int slot_of(const char *name)
+{
+    for (size_t i = 0; i < g_slots.size(); i++)
+        if (g_slots[i].name == name)
+            return (int)i;
+    g_slots.emplace_back();
+    g_slots.back().name = name;
+    return (int)g_slots.size() - 1;
+}
+
+static hipEvent_t get_event()
+{
+    if (!g_pool.empty()) {
+        hipEvent_t e = g_pool.back();
+        g_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess)
+        return nullptr;
+    return e;
+}
+
+static void resolve(TimerSlot &s)
+{
+    for (auto &p : s.pending) {
+        float ms = 0;
+        if (hipEventSynchronize(p.second) == hipSuccess && hipEventElapsedTime(&ms, p.first, p.second) == hipSuccess) {
+            s.total_ms += ms;
+            s.launches++;
+        }
+        g_pool.push_back(p.first);
+        g_pool.push_back(p.second);
+    }
+    s.pending.clear();
+}
+
+KernelTimer::KernelTimer(const char *name, hipStream_t s) : slot_(-1), s_(s), start_(nullptr), stop_(nullptr), on_(false)
+{
+    std::lock_guard<std::mutex> g(g_tmu);
+    if (!g_prof_on)
+        return;
+    slot_ = slot_of(name);
+    start_ = get_event();
+    stop_ = get_event();
+    if (!start_ || !stop_)
+        return;
+    on_ = hipEventRecord(start_, s_) == hipSuccess;
+}
+
+KernelTimer::~KernelTimer()
+{
+    if (!on_)
+        return;
+    (void)hipEventRecord(stop_, s_);
+    std::lock_guard<std::mutex> g(g_tmu);
+    g_slots[slot_].pending.emplace_back(start_, stop_);
+}
+
+} // namespace brx
+
+using namespace brx;
+
+extern "C" {
+
+const char *brx_strerror(int status)
+{
+    switch (status) {
+    case BRX_OK: return "ok";
+    case BRX_ERR_ARG: return "bad argument";
+    case BRX_ERR_NOMEM: return "out of memory";
+    case BRX_ERR_HIP: return "HIP runtime error";
+    case BRX_ERR_NODEVICE: return "no usable GPU (no CPU fallback)";
+    case BRX_ERR_FORMAT: return "malformed input";
+    case BRX_ERR_UNSUPPORTED: return "not implemented";
+    case BRX_ERR_OVERFLOW: return "output buffer too small";
+    default: return "unknown status";
+    }
+}
+
+const char *brx_last_error(void) { return g_err; }
+
+int brx_version(void) { return 100; }
+
+int brx_device_count(int *n)
+{
+    if (!n)
+        return BRX_ERR_ARG;
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        c = 0;
+    }
+    *n = c;
+    return BRX_OK;
+}
+
+int brx_profile_enable(int on)
+{
+    std::lock_guard<std::mutex> g(g_tmu);
+    g_prof_on = on != 0;
+    return BRX_OK;
+}
+
+int brx_profile_reset(void)
+{
+    std::lock_guard<std::mutex> g(g_tmu);
+    for (auto &s : g_slots) {
+        resolve(s);
+        s.total_ms = 0;
+        s.launches = 0;
+    }
+    return BRX_OK;
+}
+
+int brx_profile_get(const char *kernel, double *total_ms, uint64_t *launches)
+{
+    if (!kernel)
+        return BRX_ERR_ARG;
+    std::lock_guard<std::mutex> g(g_tmu);
+    for (auto &s : g_slots)
+        if (s.name == kernel) {
+            resolve(s);
+            if (total_ms)
+                *total_ms = s.total_ms;
+            if (launches)
+                *launches = s.launches;
+            return BRX_OK;
+        }
+    if (total_ms)
+        *total_ms = 0;
+    if (launches)
+        *launches = 0;
+    return BRX_OK;
+}
+
+int brx_profile_names(char *buf, size_t cap)
+{
+    if (!buf || cap == 0)
+        return BRX_ERR_ARG;
+    std::lock_guard<std::mutex> g(g_tmu);
+    std::string s;
+    for (auto &t : g_slots) {
+        if (!s.empty())
+            s += ",";
+        s += t.name;
+    }
+    snprintf(buf, cap, "%s", s.c_str());
+    return BRX_OK;
+}
+
+void brx_buf_free(void *p) { free(p); }
+
+} // extern "C"

@@ -1,0 +1,741 @@
+// Per-read correction scan on gfx950.
+//
+// Reference: Corrector::correct (src/correct/mod.rs:53-107), Exist<S>::correct_error
+// (src/correct/exist/mod.rs:112-150), ScenarioOne (src/correct/exist/one.rs:33-74),
+// run_correction's per-record body (src/lib.rs:42-55).
+//
+// Execution model.  The reference scan is sequential inside a read (i, kmer, previous and the
+// output length are loop carried) but every decision is a KmerSet::get, i.e. a random 1-bit
+// probe into a 2^(2k-4)-byte table in HBM.  A read is walked by a GROUP of G lanes of one
+// wavefront (G = 16/32/64, several reads per wave) that runs a small state machine; in every
+// ROUND each lane of every group issues at most one probe, all probes of the wave go out in one
+// global_load, and the group then reduces its G answers with a wave ballot:
+//
+//   SCAN   lanes probe the next G positions speculatively (lane l rolls kmer+bases[i..i+l]);
+//          the ballot gives a G-bit solidity mask; the first `!solid && previous` bit is the
+//          reference's error trigger; positions before it are accepted (copied to the output).
+//   ALTS   4 lanes probe the alternatives of the last base       (alt_nucs, mod.rs:114-128)
+//   SCEN   3*c lanes probe the c look-ahead k-mers of I/S/D      (get_score, exist/mod.rs:21-47)
+//   MORE   <=3 lanes probe the tie-break k-mer                   (one_more, exist/mod.rs:49-70)
+//
+// The machine reproduces the reference's results exactly; only the order in which probes are
+// issued differs (probes are pure).  Output goes to a per-read slot of a staging buffer
+// (capacity = input length * (1 + slack/4) + 64); the reverse pass reads its input back to
+// front instead of materialising a reversed copy (src/lib.rs:111 reverses, does not complement).
+#include "brx_internal.hpp"
+
+#include <stdlib.h>
+#include <string.h>
+
+using namespace brx;
+
+namespace brx {
+uint64_t scan_tmp_bytes(uint32_t n);
+int exclusive_scan_lens(const uint32_t *d_lens, uint32_t n, uint64_t *d_tmp, uint64_t *d_out_offsets,
+                        unsigned long long *d_total, hipStream_t s);
+int upload_batch(const uint8_t *bases, const uint64_t *offsets, uint32_t n_reads, uint8_t **d_bases, uint64_t *bases_cap,
+                 uint64_t **d_off, uint64_t *off_cap, uint64_t *total, hipStream_t stream);
+}
+
+namespace {
+
+// control block layout (u64 words)
+enum { CTL_WORK = 0, CTL_OVERFLOW = 1, CTL_ROUNDS = 2, CTL_PROBES = 3, CTL_TRIGGERS = 4, CTL_FIXES = 5, CTL_TOTAL = 6, CTL_N = 8 };
+
+struct PassParams {
+    const uint32_t *bits;
+    int k;
+    int c;            // confirm
+    uint32_t n_reads;
+    const uint64_t *offsets; // original batch offsets (n_reads+1), relative to batch start
+    // input view
+    const uint8_t *in;       // original bases or staging buffer
+    const uint32_t *in_lens; // nullptr => lengths from offsets (original batch)
+    int in_staged;           // 0: read r starts at offsets[r]; 1: at slot(r)
+    int flip;                // read the input back to front
+    // output view (always staged)
+    uint8_t *out;
+    uint32_t *out_lens;
+    uint32_t slack;          // slot(r) = o + (o>>2)*slack + 64*r
+    unsigned long long *ctrl;
+};
+
+__device__ __forceinline__ uint64_t slot_of(uint64_t o, uint64_t r, uint32_t slack)
+{
+    return o + (o >> 2) * (uint64_t)slack + 64ull * r;
+}
+
+__device__ __forceinline__ bool probe(const uint32_t *__restrict__ bits, uint64_t fwd, int k)
+{
+    const uint64_t h = khash(fwd, k);
+    return (bits[h >> 5] >> (h & 31u)) & 1u;
+}
+
+enum { ST_INIT = 0, ST_SCAN = 1, ST_ALTS = 2, ST_SCEN = 3, ST_MORE = 4 };
+
+template <int G>
+__global__ __launch_bounds__(256) void correct_one_kernel(PassParams p)
+{
+    const int lane = threadIdx.x & 63;
+    const int gl = lane & (G - 1);
+    const int gshift = lane & ~(G - 1);
+    const uint64_t GM = (G == 64) ? ~0ull : ((1ull << (G & 63)) - 1ull);
+    const int k = p.k;
+    const uint32_t c = (uint32_t)p.c;
+    const uint64_t mask = kmask(k);
+
+    // group-uniform state (replicated in every lane of the group)
+    uint32_t r = 0, n = 0, cap = 0, i = 0, olen = 0;
+    const uint8_t *in = nullptr;
+    uint8_t *out = nullptr;
+    uint64_t kmer = 0, corr = 0;
+    bool prev = false, have = false;
+    int st = ST_INIT;
+    uint32_t sub = 0, failmask = 0, passmask = 0;
+    uint8_t ch_t = 0;
+    // statistics
+    uint32_t n_rounds = 0, n_probes = 0, n_trig = 0, n_fix = 0;
+
+    auto fetch = [&]() {
+        unsigned long long w = 0;
+        if (gl == 0)
+            w = atomicAdd(p.ctrl + CTL_WORK, 1ull);
+        w = __shfl(w, gshift);
+        if (w >= (unsigned long long)p.n_reads) {
+            have = false;
+            return;
+        }
+        have = true;
+        r = (uint32_t)w;
+        const uint64_t o0 = p.offsets[r], o1 = p.offsets[r + 1];
+        if (p.in_staged) {
+            in = p.in + slot_of(o0, r, p.slack);
+            n = p.in_lens[r];
+        } else {
+            in = p.in + o0;
+            n = (uint32_t)(o1 - o0);
+        }
+        const uint64_t s0 = slot_of(o0, r, p.slack), s1 = slot_of(o1, (uint64_t)r + 1, p.slack);
+        out = p.out + s0;
+        cap = (uint32_t)(s1 - s0);
+        st = ST_INIT;
+        i = 0;
+        olen = 0;
+    };
+    auto ld = [&](uint32_t j) -> uint8_t { return in[p.flip ? (n - 1u - j) : j]; };
+    auto finish = [&]() {
+        if (gl == 0)
+            p.out_lens[r] = olen;
+        fetch();
+    };
+    auto overflow = [&]() {
+        if (gl == 0) {
+            p.out_lens[r] = 0xffffffffu;
+            atomicAdd(p.ctrl + CTL_OVERFLOW, 1ull);
+        }
+        fetch();
+    };
+
+    fetch();
+
+    while (__any(have)) {
+        bool do_probe = false;
+        uint64_t pk = 0;
+        uint8_t ch = 0;
+        uint32_t sc_s = 0;      // scenario index of this lane in SCEN
+        bool sc_active = false;
+
+        // ---------------- phase 1: choose this round's probe --------------------------------
+        if (have) {
+            n_rounds += (gl == 0);
+            if (st == ST_INIT) {
+                if (n < (uint32_t)k) {
+                    // mod.rs:56-58: shorter than k, returned verbatim
+                    if (n > cap) {
+                        // cannot happen (cap >= n + 64) but keep the invariant explicit
+                    }
+                    for (uint32_t j = gl; j < n; j += G)
+                        out[j] = ld(j);
+                    olen = n;
+                } else {
+                    uint64_t km = 0;
+                    for (int j = 0; j < k; j++)
+                        km = (km << 2) | nuc2bit(ld((uint32_t)j));
+                    kmer = km;
+                    for (uint32_t j = gl; j < (uint32_t)k; j += G)
+                        out[j] = ld(j);
+                    olen = (uint32_t)k;
+                    i = (uint32_t)k;
+                    do_probe = (gl == 0);
+                    pk = kmer;
+                }
+            } else if (st == ST_SCAN) {
+                const uint32_t pos = i + (uint32_t)gl;
+                const bool valid = pos < n;
+                ch = valid ? ld(pos) : (uint8_t)0;
+                // inclusive concat-scan of the 2-bit codes over the lanes of the group
+                uint64_t val = nuc2bit(ch);
+#pragma unroll
+                for (int d = 1; d < G && d < 32; d <<= 1) {
+                    const uint64_t other = __shfl_up(val, d, G);
+                    if (gl >= d)
+                        val |= other << (2 * d);
+                }
+                const int nb = gl + 1;
+                pk = (nb >= k) ? (val & mask) : (((kmer << (2 * nb)) | val) & mask);
+                do_probe = valid;
+            } else if (st == ST_ALTS) {
+                do_probe = gl < 4;
+                pk = add_nuc(kmer >> 2, (uint64_t)gl, mask);
+            } else if (st == ST_SCEN) {
+                const uint32_t e = sub * G + (uint32_t)gl;
+                sc_active = e < 3u * c;
+                sc_s = sc_active ? e / c : 0u;
+                const uint32_t j = sc_active ? e % c : 0u;
+                const uint32_t off = 2u - sc_s; // I:2 S:1 D:0 (one.rs:57-63)
+                sc_active = sc_active && !((failmask >> sc_s) & 1u);
+                if (sc_active) {
+                    pk = corr;
+                    for (uint32_t q = 0; q <= j; q++)
+                        pk = add_nuc(pk, nuc2bit(ld(i + off + q)), mask);
+                    do_probe = true;
+                }
+            } else { // ST_MORE
+                if (gl < 3 && ((passmask >> gl) & 1u)) {
+                    const uint32_t off = 2u - (uint32_t)gl;
+                    const uint32_t rem = n - i;
+                    if (rem > c + off + 1u) { // exist/mod.rs:54
+                        pk = corr;
+                        for (uint32_t q = 0; q <= c; q++)
+                            pk = add_nuc(pk, nuc2bit(ld(i + off + q)), mask);
+                        do_probe = true;
+                    }
+                }
+            }
+        }
+
+        // ---------------- phase 2: one probe per lane, whole wave at once ---------------------
+        bool sol = false;
+        if (do_probe) {
+            sol = probe(p.bits, pk, k);
+            n_probes++;
+        }
+        const uint64_t ball = __ballot(sol);
+        const uint64_t gmask = (ball >> gshift) & GM;
+
+        // ---------------- phase 3: group-uniform transitions ----------------------------------
+        if (have) {
+            bool fail = false;   // correct_error returned None
+            int apply_s = -1;    // scenario to apply
+            if (st == ST_INIT) {
+                if (n < (uint32_t)k) {
+                    finish();
+                } else {
+                    prev = gmask & 1ull; // mod.rs:67
+                    if (i >= n)
+                        finish();
+                    else
+                        st = ST_SCAN;
+                }
+            } else if (st == ST_SCAN) {
+                const uint32_t left = n - i;
+                const uint32_t nvalid = left < (uint32_t)G ? left : (uint32_t)G;
+                const uint64_t vmask = (nvalid >= 64) ? ~0ull : ((1ull << nvalid) - 1ull);
+                const uint64_t prevmask = (gmask << 1) | (prev ? 1ull : 0ull);
+                const uint64_t trig = ~gmask & prevmask & vmask; // mod.rs:73
+                const uint32_t nacc = trig ? (uint32_t)__builtin_ctzll(trig) : nvalid;
+                if (olen + nacc + 1u > cap) {
+                    overflow();
+                } else {
+                    if ((uint32_t)gl < nacc)
+                        out[olen + (uint32_t)gl] = ch; // mod.rs:100
+                    olen += nacc;
+                    i += nacc;
+                    if (trig) {
+                        kmer = __shfl(pk, gshift + (int)nacc);
+                        ch_t = (uint8_t)__shfl((int)ch, gshift + (int)nacc);
+                        st = ST_ALTS;
+                        n_trig += (gl == 0);
+                    } else {
+                        kmer = __shfl(pk, gshift + (int)nacc - 1);
+                        prev = (gmask >> (nacc - 1)) & 1ull; // mod.rs:99
+                        if (i >= n)
+                            finish();
+                    }
+                }
+            } else if (st == ST_ALTS) {
+                const uint32_t am = (uint32_t)(gmask & 0xfull);
+                if (__popc(am) != 1) {
+                    fail = true; // exist/mod.rs:123-126
+                } else {
+                    corr = add_nuc(kmer >> 2, (uint64_t)(__ffs(am) - 1), mask);
+                    const uint32_t rem = n - i;
+                    failmask = 0;
+                    for (uint32_t s = 0; s < 3; s++)
+                        if ((2u - s) + c > rem) // exist/mod.rs:27-29
+                            failmask |= 1u << s;
+                    if (failmask == 7u || c == 0u) {
+                        // c == 0: every scenario trivially scores 0 == c; handled below
+                        if (c == 0u) {
+                            passmask = 7u & ~failmask;
+                            if (passmask == 0)
+                                fail = true;
+                            else if (__popc(passmask) == 1)
+                                apply_s = __ffs(passmask) - 1;
+                            else
+                                st = ST_MORE;
+                        } else {
+                            fail = true;
+                        }
+                    } else {
+                        sub = 0;
+                        st = ST_SCEN;
+                    }
+                }
+            } else if (st == ST_SCEN) {
+                const bool bad = sc_active && !sol;
+#pragma unroll
+                for (uint32_t s = 0; s < 3; s++) {
+                    const uint64_t b = (__ballot(bad && sc_s == s) >> gshift) & GM;
+                    if (b)
+                        failmask |= 1u << s;
+                }
+                sub++;
+                if (failmask == 7u) {
+                    fail = true; // exist/mod.rs:132-134
+                } else if (sub * G >= 3u * c) {
+                    passmask = 7u & ~failmask;
+                    if (__popc(passmask) == 1)
+                        apply_s = __ffs(passmask) - 1; // exist/mod.rs:135-137
+                    else
+                        st = ST_MORE;
+                }
+            } else { // ST_MORE
+                const uint32_t keep = (uint32_t)(gmask & 7ull) & passmask;
+                if (__popc(keep) == 1)
+                    apply_s = __ffs(keep) - 1; // exist/mod.rs:143-144
+                else
+                    fail = true;
+            }
+
+            if (fail) {
+                // mod.rs:91-96
+                if (olen + 2u > cap) {
+                    overflow();
+                } else {
+                    if (gl == 0)
+                        out[olen] = ch_t;
+                    olen += 1;
+                    i += 1;
+                    prev = false;
+                    if (i >= n)
+                        finish();
+                    else
+                        st = ST_SCAN;
+                }
+            } else if (apply_s >= 0) {
+                // mod.rs:75-89 with one.rs:65-71
+                if (olen + 2u > cap) {
+                    overflow();
+                } else {
+                    if (gl == 0)
+                        out[olen] = bit2nuc(corr & 3ull);
+                    olen += 1;
+                    kmer = corr;
+                    prev = true;
+                    i += 2u - (uint32_t)apply_s;
+                    n_fix += (gl == 0);
+                    if (i >= n)
+                        finish();
+                    else
+                        st = ST_SCAN;
+                }
+            }
+        }
+    }
+
+    // statistics: one atomic per wave per counter
+    uint32_t v;
+    v = n_rounds;
+    for (int d = 32; d > 0; d >>= 1)
+        v += __shfl_down(v, d);
+    if (lane == 0 && v)
+        atomicAdd(p.ctrl + CTL_ROUNDS, (unsigned long long)v);
+    v = n_probes;
+    for (int d = 32; d > 0; d >>= 1)
+        v += __shfl_down(v, d);
+    if (lane == 0 && v)
+        atomicAdd(p.ctrl + CTL_PROBES, (unsigned long long)v);
+    v = n_trig;
+    for (int d = 32; d > 0; d >>= 1)
+        v += __shfl_down(v, d);
+    if (lane == 0 && v)
+        atomicAdd(p.ctrl + CTL_TRIGGERS, (unsigned long long)v);
+    v = n_fix;
+    for (int d = 32; d > 0; d >>= 1)
+        v += __shfl_down(v, d);
+    if (lane == 0 && v)
+        atomicAdd(p.ctrl + CTL_FIXES, (unsigned long long)v);
+}
+
+// one workgroup per read (grid-stride): staged slot -> compact output, reversing if needed
+__global__ __launch_bounds__(256) void compact_kernel(const uint8_t *__restrict__ stage, const uint32_t *__restrict__ lens,
+                                                      const uint64_t *__restrict__ offsets, uint32_t n_reads,
+                                                      uint32_t slack, int reversed, const uint64_t *__restrict__ out_offsets,
+                                                      uint8_t *__restrict__ out)
+{
+    for (uint32_t r = blockIdx.x; r < n_reads; r += gridDim.x) {
+        const uint8_t *src = stage + slot_of(offsets[r], r, slack);
+        const uint32_t n = lens[r];
+        uint8_t *dst = out + out_offsets[r];
+        if (reversed) {
+            for (uint32_t j = threadIdx.x; j < n; j += blockDim.x)
+                dst[j] = src[n - 1u - j];
+        } else {
+            for (uint32_t j = threadIdx.x; j < n; j += blockDim.x)
+                dst[j] = src[j];
+        }
+    }
+}
+
+int ensure(void **p, uint64_t *cap, uint64_t need)
+{
+    if (need <= *cap && *p)
+        return BRX_OK;
+    if (*p)
+        (void)hipFree(*p);
+    *p = nullptr;
+    *cap = 0;
+    uint64_t want = need + need / 8 + 256;
+    hipError_t e = hipMalloc(p, want);
+    if (e != hipSuccess) {
+        set_error("hipMalloc(%llu B workspace): %s", (unsigned long long)want, hipGetErrorString(e));
+        return BRX_ERR_NOMEM;
+    }
+    *cap = want;
+    return BRX_OK;
+}
+
+int group_width()
+{
+    // lanes per read; BRX_GROUP overrides (read on every launch so tests can sweep it)
+    const char *e = getenv("BRX_GROUP");
+    const int g = e ? atoi(e) : 16;
+    return (g == 16 || g == 32 || g == 64) ? g : 16;
+}
+
+int launch_pass(const brx_chain *ch, const PassParams &p, int method, hipStream_t s)
+{
+    if (method != BRX_ONE) {
+        set_error("correction method %d not implemented on the GPU path yet", method);
+        return BRX_ERR_UNSUPPORTED;
+    }
+    (void)ch;
+    const int G = group_width();
+    const uint32_t groups_per_block = 256 / G;
+    // persistent-ish grid: enough groups to fill the chip, reads pulled from a work counter
+    uint64_t want_blocks = ((uint64_t)p.n_reads + groups_per_block - 1) / groups_per_block;
+    const uint64_t max_blocks = 256ull * 8ull;
+    if (want_blocks > max_blocks)
+        want_blocks = max_blocks;
+    if (want_blocks < 1)
+        want_blocks = 1;
+    KernelTimer t("correct_pass", s);
+    if (G == 16)
+        correct_one_kernel<16><<<(int)want_blocks, 256, 0, s>>>(p);
+    else if (G == 32)
+        correct_one_kernel<32><<<(int)want_blocks, 256, 0, s>>>(p);
+    else
+        correct_one_kernel<64><<<(int)want_blocks, 256, 0, s>>>(p);
+    BRX_HIP(hipGetLastError());
+    return BRX_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int brx_chain_new(const brx_set_t *set, const brx_method_t *methods, uint32_t n_methods, bool two_side,
+                  brx_chain_t **out)
+{
+    if (!set || !out || (!methods && n_methods)) {
+        set_error("null argument");
+        return BRX_ERR_ARG;
+    }
+    for (uint32_t m = 0; m < n_methods; m++)
+        if (methods[m].method > BRX_GAP_SIZE) {
+            set_error("unknown correction method %u", methods[m].method);
+            return BRX_ERR_ARG;
+        }
+    BRX_TRY(use_device(set->device));
+    brx_chain *ch = new brx_chain();
+    ch->set = set;
+    ch->device = set->device;
+    ch->methods.assign(methods, methods + n_methods);
+    ch->two_side = two_side;
+    ch->stream = nullptr;
+    ch->d_stage[0] = ch->d_stage[1] = nullptr;
+    ch->stage_bytes = 0;
+    ch->d_lens[0] = ch->d_lens[1] = nullptr;
+    ch->lens_cap = 0;
+    ch->d_scan_tmp = nullptr;
+    ch->scan_tmp_cap = 0;
+    ch->d_ctrl = nullptr;
+    ch->h_ctrl = nullptr;
+    ch->d_in = nullptr;
+    ch->d_in_cap = 0;
+    ch->d_off = nullptr;
+    ch->d_off_cap = 0;
+    ch->d_out = nullptr;
+    ch->d_out_cap = 0;
+    ch->d_out_off = nullptr;
+    ch->d_out_off_cap = 0;
+    memset(ch->last_stats, 0, sizeof(ch->last_stats));
+    hipError_t e = hipStreamCreateWithFlags(&ch->stream, hipStreamNonBlocking);
+    if (e == hipSuccess)
+        e = hipMalloc((void **)&ch->d_ctrl, CTL_N * 8);
+    if (e == hipSuccess)
+        e = hipHostMalloc((void **)&ch->h_ctrl, CTL_N * 8, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        set_error("chain alloc: %s", hipGetErrorString(e));
+        brx_chain_free(ch);
+        return BRX_ERR_HIP;
+    }
+    *out = ch;
+    return BRX_OK;
+}
+
+int brx_chain_correct_batch_device(brx_chain_t *ch, const uint8_t *d_bases, const uint64_t *d_offsets,
+                                   uint32_t n_reads, uint64_t total_bases, uint8_t *d_out, uint64_t out_cap,
+                                   uint64_t *d_out_offsets, uint64_t *out_total, void *stream)
+{
+    if (!ch || !d_offsets || !d_out_offsets || !out_total || (!d_bases && total_bases) || (!d_out && out_cap)) {
+        set_error("null argument");
+        return BRX_ERR_ARG;
+    }
+    BRX_TRY(use_device(ch->device));
+    std::lock_guard<std::mutex> g(ch->mu);
+    hipStream_t s = stream ? (hipStream_t)stream : ch->stream;
+    *out_total = 0;
+    if (n_reads == 0) {
+        BRX_HIP(hipMemsetAsync(d_out_offsets, 0, 8, s));
+        BRX_HIP(hipStreamSynchronize(s));
+        return BRX_OK;
+    }
+    const int k = ch->set->k;
+    if ((k & 1) == 0) {
+        set_error("correction needs an odd k (parity-canonical set), got %d", k);
+        return BRX_ERR_ARG;
+    }
+
+    // (lens, scan scratch) do not depend on slack
+    {
+        uint64_t cap_b = ch->lens_cap * 4;
+        const uint64_t need = (uint64_t)n_reads * 4;
+        if (need > cap_b || !ch->d_lens[0]) {
+            for (int q = 0; q < 2; q++) {
+                if (ch->d_lens[q])
+                    (void)hipFree(ch->d_lens[q]);
+                ch->d_lens[q] = nullptr;
+            }
+            const uint64_t want = (uint64_t)n_reads + n_reads / 8 + 64;
+            BRX_HIP(hipMalloc((void **)&ch->d_lens[0], want * 4));
+            BRX_HIP(hipMalloc((void **)&ch->d_lens[1], want * 4));
+            ch->lens_cap = want;
+        }
+        uint64_t tmp_bytes = ch->scan_tmp_cap;
+        BRX_TRY(ensure((void **)&ch->d_scan_tmp, &tmp_bytes, scan_tmp_bytes(n_reads)));
+        ch->scan_tmp_cap = tmp_bytes;
+    }
+
+    const int n_dirs = ch->two_side ? 1 : 2;
+    const int n_methods = (int)ch->methods.size();
+    uint64_t stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+
+    for (uint32_t slack = 1, attempt = 0;; slack *= 4, attempt++) {
+        if (attempt > 6) {
+            set_error("correction output does not fit 4096x the input size; giving up");
+            return BRX_ERR_OVERFLOW;
+        }
+        const uint64_t stage_need = total_bases + (total_bases >> 2) * slack + 64ull * ((uint64_t)n_reads + 1) + 64;
+        if (stage_need > ch->stage_bytes || !ch->d_stage[0]) {
+            for (int q = 0; q < 2; q++) {
+                if (ch->d_stage[q])
+                    (void)hipFree(ch->d_stage[q]);
+                ch->d_stage[q] = nullptr;
+            }
+            ch->stage_bytes = 0;
+            BRX_HIP(hipMalloc((void **)&ch->d_stage[0], stage_need));
+            BRX_HIP(hipMalloc((void **)&ch->d_stage[1], stage_need));
+            ch->stage_bytes = stage_need;
+        }
+
+        // the chain: src/lib.rs:44-55.  buffer "rev" = stored back to front w.r.t. the original read
+        const uint8_t *cur = d_bases;
+        const uint32_t *cur_lens = nullptr;
+        int cur_staged = 0, cur_rev = 0, pp = 0;
+        bool any_overflow = false;
+        BRX_HIP(hipMemsetAsync(ch->d_ctrl, 0, CTL_N * 8, s));
+        for (int dir = 0; dir < n_dirs && !any_overflow; dir++) {
+            for (int m = 0; m < n_methods; m++) {
+                PassParams p;
+                p.bits = ch->set->d_bits;
+                p.k = k;
+                p.c = ch->methods[m].confirm;
+                p.n_reads = n_reads;
+                p.offsets = d_offsets;
+                p.in = cur;
+                p.in_lens = cur_lens;
+                p.in_staged = cur_staged;
+                p.flip = (cur_rev != dir);
+                p.out = ch->d_stage[pp];
+                p.out_lens = ch->d_lens[pp];
+                p.slack = slack;
+                p.ctrl = (unsigned long long *)ch->d_ctrl;
+                BRX_HIP(hipMemsetAsync(ch->d_ctrl + CTL_WORK, 0, 8, s));
+                BRX_TRY(launch_pass(ch, p, ch->methods[m].method, s));
+                cur = ch->d_stage[pp];
+                cur_lens = ch->d_lens[pp];
+                cur_staged = 1;
+                cur_rev = dir;
+                pp ^= 1;
+            }
+        }
+        if (n_methods == 0) {
+            // no corrector: identity (a reverse of a reverse).  Copy through one staged pass-less path.
+            set_error("empty method list");
+            return BRX_ERR_ARG;
+        }
+        BRX_HIP(hipMemcpyAsync(ch->h_ctrl, ch->d_ctrl, CTL_N * 8, hipMemcpyDeviceToHost, s));
+        BRX_HIP(hipStreamSynchronize(s));
+        stats[4] = attempt;
+        if (ch->h_ctrl[CTL_OVERFLOW] != 0)
+            continue; // some read outgrew its slot: redo the batch with 4x the slack
+        stats[0] = ch->h_ctrl[CTL_ROUNDS];
+        stats[1] = ch->h_ctrl[CTL_PROBES];
+        stats[2] = ch->h_ctrl[CTL_TRIGGERS];
+        stats[3] = ch->h_ctrl[CTL_FIXES];
+
+        // out_offsets = exclusive scan of final lengths
+        BRX_TRY(exclusive_scan_lens(cur_lens, n_reads, ch->d_scan_tmp, d_out_offsets,
+                                    (unsigned long long *)(ch->d_ctrl + CTL_TOTAL), s));
+        BRX_HIP(hipMemcpyAsync(ch->h_ctrl, ch->d_ctrl, CTL_N * 8, hipMemcpyDeviceToHost, s));
+        BRX_HIP(hipStreamSynchronize(s));
+        const uint64_t total = ch->h_ctrl[CTL_TOTAL];
+        *out_total = total;
+        memcpy(ch->last_stats, stats, sizeof(stats));
+        if (total > out_cap) {
+            set_error("corrected batch needs %llu bytes, output buffer has %llu", (unsigned long long)total,
+                      (unsigned long long)out_cap);
+            return BRX_ERR_OVERFLOW;
+        }
+        {
+            KernelTimer t("compact", s);
+            const uint32_t grid = n_reads < (1u << 20) ? n_reads : (1u << 20);
+            compact_kernel<<<grid, 256, 0, s>>>(cur, cur_lens, d_offsets, n_reads, slack, cur_rev, d_out_offsets, d_out);
+        }
+        BRX_HIP(hipStreamSynchronize(s));
+        return BRX_OK;
+    }
+}
+
+int brx_chain_correct_batch(brx_chain_t *ch, const uint8_t *bases, const uint64_t *offsets, uint32_t n_reads,
+                            uint8_t **out_bases, uint64_t **out_offsets)
+{
+    if (!ch || !offsets || !out_bases || !out_offsets || (!bases && n_reads)) {
+        set_error("null argument");
+        return BRX_ERR_ARG;
+    }
+    *out_bases = nullptr;
+    *out_offsets = nullptr;
+    BRX_TRY(use_device(ch->device));
+    uint64_t total = 0;
+    {
+        std::lock_guard<std::mutex> g(ch->mu);
+        BRX_TRY(upload_batch(bases, offsets, n_reads, &ch->d_in, &ch->d_in_cap, &ch->d_off, &ch->d_off_cap, &total,
+                             ch->stream));
+        uint64_t cap_b = ch->d_out_off_cap * 8;
+        BRX_TRY(ensure((void **)&ch->d_out_off, &cap_b, ((uint64_t)n_reads + 1) * 8));
+        ch->d_out_off_cap = cap_b / 8;
+    }
+    uint64_t out_total = 0;
+    uint64_t want = total + total / 16 + 4096;
+    for (int attempt = 0; attempt < 3; attempt++) {
+        {
+            std::lock_guard<std::mutex> g(ch->mu);
+            BRX_TRY(ensure((void **)&ch->d_out, &ch->d_out_cap, want));
+        }
+        int st = brx_chain_correct_batch_device(ch, ch->d_in, ch->d_off, n_reads, total, ch->d_out, ch->d_out_cap,
+                                                ch->d_out_off, &out_total, ch->stream);
+        if (st == BRX_ERR_OVERFLOW && out_total > ch->d_out_cap) {
+            want = out_total + 64;
+            continue;
+        }
+        if (st != BRX_OK)
+            return st;
+        break;
+    }
+    uint8_t *hb = (uint8_t *)malloc(out_total ? out_total : 1);
+    uint64_t *ho = (uint64_t *)malloc(((size_t)n_reads + 1) * 8);
+    if (!hb || !ho) {
+        free(hb);
+        free(ho);
+        set_error("host malloc failed");
+        return BRX_ERR_NOMEM;
+    }
+    hipError_t e = hipSuccess;
+    if (out_total)
+        e = hipMemcpy(hb, ch->d_out, out_total, hipMemcpyDeviceToHost);
+    if (e == hipSuccess)
+        e = hipMemcpy(ho, ch->d_out_off, ((size_t)n_reads + 1) * 8, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) {
+        free(hb);
+        free(ho);
+        set_error("D2H: %s", hipGetErrorString(e));
+        return BRX_ERR_HIP;
+    }
+    *out_bases = hb;
+    *out_offsets = ho;
+    return BRX_OK;
+}
+
+int brx_chain_last_stats(const brx_chain_t *ch, uint64_t *stats8)
+{
+    if (!ch || !stats8)
+        return BRX_ERR_ARG;
+    memcpy(stats8, ch->last_stats, sizeof(ch->last_stats));
+    return BRX_OK;
+}
+
+void brx_chain_free(brx_chain_t *ch)
+{
+    if (!ch)
+        return;
+    if (use_device(ch->device) == BRX_OK) {
+        for (int q = 0; q < 2; q++) {
+            if (ch->d_stage[q])
+                (void)hipFree(ch->d_stage[q]);
+            if (ch->d_lens[q])
+                (void)hipFree(ch->d_lens[q]);
+        }
+        if (ch->d_scan_tmp)
+            (void)hipFree(ch->d_scan_tmp);
+        if (ch->d_ctrl)
+            (void)hipFree(ch->d_ctrl);
+        if (ch->h_ctrl)
+            (void)hipHostFree(ch->h_ctrl);
+        if (ch->d_in)
+            (void)hipFree(ch->d_in);
+        if (ch->d_off)
+            (void)hipFree(ch->d_off);
+        if (ch->d_out)
+            (void)hipFree(ch->d_out);
+        if (ch->d_out_off)
+            (void)hipFree(ch->d_out_off);
+        if (ch->stream)
+            (void)hipStreamDestroy(ch->stream);
+    }
+    delete ch;
+}
+
+} // extern "C"

@@ -1,0 +1,105 @@
+// Internal declarations shared by the translation units of libbrx.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdarg.h>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/brx.h"
+#include "brx_kmer.hpp"
+
+namespace brx {
+
+void set_error(const char *fmt, ...);
+
+#define BRX_HIP(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t _e = (expr);                                                                    \
+        if (_e != hipSuccess) {                                                                    \
+            brx::set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e));   \
+            return (_e == hipErrorOutOfMemory) ? BRX_ERR_NOMEM : BRX_ERR_HIP;                      \
+        }                                                                                          \
+    } while (0)
+
+#define BRX_TRY(expr)                                                                              \
+    do {                                                                                           \
+        int _s = (expr);                                                                           \
+        if (_s != BRX_OK)                                                                          \
+            return _s;                                                                             \
+    } while (0)
+
+// BRX_OK if `device` is a usable GPU and has been made current
+int use_device(int device);
+
+// ---- per-kernel HIP-event timers -----------------------------------------------------------
+// Usage: { KernelTimer t("correct_pass", stream); launch<<<...,stream>>>(); }
+// Events are recorded on the launch stream and resolved lazily by brx_profile_get.
+class KernelTimer {
+  public:
+    KernelTimer(const char *name, hipStream_t s);
+    ~KernelTimer();
+
+  private:
+    int slot_;
+    hipStream_t s_;
+    hipEvent_t start_, stop_;
+    bool on_;
+};
+
+// number of 32-bit words of the bitset for a given k (at least 1)
+inline uint64_t set_nbits(int k) { return 1ull << (2 * k - 1); }
+inline uint64_t set_nwords(int k) { uint64_t b = set_nbits(k); return b < 32 ? 1 : b / 32; }
+inline uint64_t set_nbytes_file(int k) { return (set_nbits(k) + 7) / 8; }
+
+} // namespace brx
+
+struct brx_set {
+    int k;
+    int device;
+    uint64_t nwords;   // u32 words
+    uint32_t *d_bits;  // nwords, zero padded
+};
+
+struct brx_counter {
+    int k;
+    int device;
+    int strategy;
+    // dense: u8 table packed in u32 words (2^(2k-1) bytes, padded to 32 B)
+    uint32_t *d_counts;
+    uint64_t count_bytes;
+    // sorted: canonical hashes
+    uint64_t *d_keys;
+    uint64_t n_keys, cap_keys;
+    hipStream_t stream; // owned, used by host-pointer entry points
+    std::mutex mu;
+};
+
+struct brx_chain {
+    const brx_set *set;
+    int device;
+    std::vector<brx_method_t> methods;
+    bool two_side;
+    hipStream_t stream; // owned
+    // workspace (grown on demand)
+    uint8_t *d_stage[2];
+    uint64_t stage_bytes;
+    uint32_t *d_lens[2];
+    uint64_t lens_cap;
+    uint64_t *d_scan_tmp;
+    uint64_t scan_tmp_cap;
+    uint64_t *d_ctrl;   // device control block (work counter, overflow, stats)
+    uint64_t *h_ctrl;   // pinned mirror
+    // host-entry staging
+    uint8_t *d_in;
+    uint64_t d_in_cap;
+    uint64_t *d_off;
+    uint64_t d_off_cap;
+    uint8_t *d_out;
+    uint64_t d_out_cap;
+    uint64_t *d_out_off;
+    uint64_t d_out_off_cap;
+    uint64_t last_stats[8];
+    std::mutex mu;
+};

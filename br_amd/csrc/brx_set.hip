@@ -1,0 +1,600 @@
+// Solid-k-mer set: packed canonical bitset in HBM, built by counting.
+//
+// Reference path: src/main.rs:72-115 (Counter::new -> count_fasta -> Solid::from_count),
+// src/set/pcon.rs:13-196 (Pcon wrapper, get/k), pcon::solid::Solid (bit layout).
+//
+// HBM layout
+//   bitset : u32[2^(2k-1)/32]; bit i (= canonical>>1) is bit (i & 31) of word (i >> 5)
+//            == bit (i & 7) of byte (i >> 3) of the .solid stream (Lsb0, little endian).
+//   counts : u8[2^(2k-1)] packed 4 per u32 word (dense strategy), saturating at 255.
+//
+// Kernels (all integer, HBM-bound; no MFMA):
+//   count_dense_kernel  one workgroup per read; each lane rolls a strip of consecutive
+//                       k-mers and does one saturating byte increment (32-bit CAS) per k-mer.
+//                       Algorithmic bytes per k-mer: 1 B base + 64 B counter line read + 64 B
+//                       write-back = 129 B.
+//   threshold_kernel    streams the count table once: 32 counts -> 1 bitset word.
+//                       2^(2k-1) B read + 2^(2k-4) B written.
+//   insert_kernel       presence-only build (Pcon::from_fasta): atomicOr of one bit per k-mer.
+//   get_kernel          n independent KmerSet::get probes.
+#include "brx_internal.hpp"
+
+#include <stdlib.h>
+#include <string.h>
+
+using namespace brx;
+
+namespace {
+
+constexpr int STRIP = 16; // consecutive k-mers rolled by one lane
+
+__device__ __forceinline__ void count_inc_u8(uint32_t *counts, uint64_t h)
+{
+    uint32_t *w = counts + (h >> 2);
+    const unsigned sh = (unsigned)(h & 3u) * 8u;
+    uint32_t old = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (;;) {
+        if (((old >> sh) & 0xffu) == 0xffu)
+            return; // saturated (pcon Counter<u8>; saturate-vs-wrap unpinned)
+        const uint32_t want = old + (1u << sh);
+        const uint32_t seen = atomicCAS(w, old, want);
+        if (seen == old)
+            return;
+        old = seen;
+    }
+}
+
+// MODE 0: dense count; MODE 1: presence insert (atomicOr into the bitset)
+template <int MODE>
+__global__ __launch_bounds__(256) void kmer_scatter_kernel(const uint8_t *__restrict__ bases,
+                                                            const uint64_t *__restrict__ offsets, uint32_t n_reads,
+                                                            int k, uint32_t *__restrict__ table)
+{
+    const uint64_t mask = kmask(k);
+    for (uint32_t r = blockIdx.x; r < n_reads; r += gridDim.x) {
+        const uint64_t s = offsets[r];
+        const uint64_t len = offsets[r + 1] - s;
+        if (len < (uint64_t)k)
+            continue;
+        const uint64_t nk = len - (uint64_t)k + 1;
+        const uint8_t *seq = bases + s;
+        for (uint64_t p0 = (uint64_t)threadIdx.x * STRIP; p0 < nk; p0 += (uint64_t)blockDim.x * STRIP) {
+            uint64_t kmer = 0;
+            for (int j = 0; j < k; j++)
+                kmer = (kmer << 2) | nuc2bit(seq[p0 + j]);
+            const uint64_t pend = (p0 + STRIP < nk) ? p0 + STRIP : nk;
+            for (uint64_t p = p0;;) {
+                const uint64_t h = khash(kmer, k);
+                if (MODE == 0)
+                    count_inc_u8(table, h);
+                else
+                    atomicOr(table + (h >> 5), 1u << (h & 31u));
+                if (++p >= pend)
+                    break;
+                kmer = add_nuc(kmer, nuc2bit(seq[p + k - 1]), mask);
+            }
+        }
+    }
+}
+
+// one lane: 32 consecutive counts (two 16-byte loads) -> one bitset word
+__global__ __launch_bounds__(256) void threshold_kernel(const uint4 *__restrict__ counts, uint64_t nwords,
+                                                        uint32_t abundance, uint32_t *__restrict__ bits)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < nwords; w += stride) {
+        const uint4 a = counts[2 * w], b = counts[2 * w + 1];
+        const uint32_t v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        uint32_t out = 0;
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                out |= (uint32_t)(((v[q] >> (8 * j)) & 0xffu) > abundance) << (4 * q + j);
+        }
+        bits[w] = out;
+    }
+}
+
+__global__ __launch_bounds__(256) void clamp_kernel(uint4 *__restrict__ counts, uint64_t nvec, uint32_t cap)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
+        uint4 a = counts[i];
+        uint32_t v[4] = {a.x, a.y, a.z, a.w};
+        bool dirty = false;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            uint32_t o = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                uint32_t c = (v[q] >> (8 * j)) & 0xffu;
+                c = c > cap ? cap : c;
+                o |= c << (8 * j);
+            }
+            dirty |= (o != v[q]);
+            v[q] = o;
+        }
+        if (dirty)
+            counts[i] = make_uint4(v[0], v[1], v[2], v[3]);
+    }
+}
+
+__global__ void get_kernel(const uint32_t *__restrict__ bits, const uint64_t *__restrict__ kmers, uint32_t n, int k,
+                           uint8_t *__restrict__ out)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    const uint64_t h = khash(kmers[i], k);
+    out[i] = (uint8_t)((bits[h >> 5] >> (h & 31u)) & 1u);
+}
+
+__global__ void set_bit_kernel(uint32_t *bits, uint64_t h, int value)
+{
+    if (value)
+        atomicOr(bits + (h >> 5), 1u << (h & 31u));
+    else
+        atomicAnd(bits + (h >> 5), ~(1u << (h & 31u)));
+}
+
+__global__ __launch_bounds__(256) void popcount_kernel(const uint32_t *__restrict__ bits, uint64_t nwords,
+                                                       unsigned long long *__restrict__ total)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    unsigned long long acc = 0;
+    for (uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < nwords; w += stride)
+        acc += (unsigned long long)__popc(bits[w]);
+    for (int d = 32; d > 0; d >>= 1)
+        acc += __shfl_down(acc, d);
+    if ((threadIdx.x & 63) == 0 && acc)
+        atomicAdd(total, acc);
+}
+
+int check_k(int k, bool need_odd)
+{
+    if (k < 1 || k > 31) {
+        set_error("k=%d out of range 1..31", k);
+        return BRX_ERR_ARG;
+    }
+    if (need_odd && (k & 1) == 0) {
+        set_error("k=%d must be odd (parity-canonical k-mers; the reference forces odd k, src/cli.rs:277-279)", k);
+        return BRX_ERR_ARG;
+    }
+    return BRX_OK;
+}
+
+int alloc_set(int k, int device, bool zero, brx_set **out)
+{
+    BRX_TRY(check_k(k, false));
+    BRX_TRY(use_device(device));
+    brx_set *s = new brx_set();
+    s->k = k;
+    s->device = device;
+    s->nwords = set_nwords(k);
+    s->d_bits = nullptr;
+    hipError_t e = hipMalloc((void **)&s->d_bits, s->nwords * 4);
+    if (e != hipSuccess) {
+        set_error("hipMalloc(%llu B bitset, k=%d): %s", (unsigned long long)(s->nwords * 4), k, hipGetErrorString(e));
+        delete s;
+        return BRX_ERR_NOMEM;
+    }
+    if (zero) {
+        e = hipMemset(s->d_bits, 0, s->nwords * 4);
+        if (e != hipSuccess) {
+            set_error("hipMemset bitset: %s", hipGetErrorString(e));
+            (void)hipFree(s->d_bits);
+            delete s;
+            return BRX_ERR_HIP;
+        }
+    }
+    *out = s;
+    return BRX_OK;
+}
+
+int grid_for(uint64_t items, int per_block, int cap = 256 * 8)
+{
+    uint64_t g = (items + per_block - 1) / per_block;
+    if (g < 1)
+        g = 1;
+    if (g > (uint64_t)cap)
+        g = cap;
+    return (int)g;
+}
+
+} // namespace
+
+namespace brx {
+// used by the correction chain and the host-pointer entry points
+int upload_batch(const uint8_t *bases, const uint64_t *offsets, uint32_t n_reads, uint8_t **d_bases, uint64_t *bases_cap,
+                 uint64_t **d_off, uint64_t *off_cap, uint64_t *total, hipStream_t stream)
+{
+    const uint64_t base0 = offsets[0];
+    const uint64_t tot = offsets[n_reads] - base0;
+    for (uint32_t r = 0; r < n_reads; r++)
+        if (offsets[r + 1] < offsets[r]) {
+            set_error("offsets not monotone at read %u", r);
+            return BRX_ERR_ARG;
+        }
+    if (tot + 64 > *bases_cap) {
+        if (*d_bases)
+            (void)hipFree(*d_bases);
+        *d_bases = nullptr;
+        *bases_cap = 0;
+        BRX_HIP(hipMalloc((void **)d_bases, tot + 64));
+        *bases_cap = tot + 64;
+    }
+    if ((uint64_t)n_reads + 1 > *off_cap) {
+        if (*d_off)
+            (void)hipFree(*d_off);
+        *d_off = nullptr;
+        *off_cap = 0;
+        BRX_HIP(hipMalloc((void **)d_off, ((uint64_t)n_reads + 1) * 8));
+        *off_cap = (uint64_t)n_reads + 1;
+    }
+    if (tot)
+        BRX_HIP(hipMemcpyAsync(*d_bases, bases + base0, tot, hipMemcpyHostToDevice, stream));
+    if (base0 == 0) {
+        BRX_HIP(hipMemcpyAsync(*d_off, offsets, ((uint64_t)n_reads + 1) * 8, hipMemcpyHostToDevice, stream));
+        BRX_HIP(hipStreamSynchronize(stream));
+    } else {
+        std::vector<uint64_t> rel((size_t)n_reads + 1);
+        for (uint32_t r = 0; r <= n_reads; r++)
+            rel[r] = offsets[r] - base0;
+        BRX_HIP(hipMemcpyAsync(*d_off, rel.data(), rel.size() * 8, hipMemcpyHostToDevice, stream));
+        BRX_HIP(hipStreamSynchronize(stream));
+    }
+    *total = tot;
+    return BRX_OK;
+}
+} // namespace brx
+
+extern "C" {
+
+int brx_set_new(uint8_t k, int device, brx_set_t **out)
+{
+    if (!out)
+        return BRX_ERR_ARG;
+    return alloc_set(k, device, true, out);
+}
+
+int brx_set_new_from_solid_bytes(const uint8_t *buf, size_t len, int device, brx_set_t **out)
+{
+    if (!buf || !out || len < 1) {
+        set_error("null/empty .solid buffer");
+        return BRX_ERR_ARG;
+    }
+    const int k = buf[0];
+    if (k < 1 || k > 31 || len - 1 != set_nbytes_file(k)) {
+        set_error(".solid stream: k=%d, %zu payload bytes, expected %llu", k, len - 1,
+                  (unsigned long long)((k >= 1 && k <= 31) ? set_nbytes_file(k) : 0));
+        return BRX_ERR_FORMAT;
+    }
+    brx_set *s = nullptr;
+    BRX_TRY(alloc_set(k, device, set_nbytes_file(k) < 4, &s));
+    hipError_t e = hipMemcpy(s->d_bits, buf + 1, len - 1, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        set_error("hipMemcpy bitset H2D: %s", hipGetErrorString(e));
+        brx_set_free(s);
+        return BRX_ERR_HIP;
+    }
+    *out = s;
+    return BRX_OK;
+}
+
+int brx_set_insert_batch(brx_set_t *set, const uint8_t *bases, const uint64_t *offsets, uint32_t n_reads)
+{
+    if (!set || !offsets || (!bases && n_reads)) {
+        set_error("null argument");
+        return BRX_ERR_ARG;
+    }
+    BRX_TRY(check_k(set->k, true));
+    BRX_TRY(use_device(set->device));
+    if (n_reads == 0)
+        return BRX_OK;
+    uint8_t *d_b = nullptr;
+    uint64_t *d_o = nullptr;
+    uint64_t bc = 0, oc = 0, tot = 0;
+    int st = upload_batch(bases, offsets, n_reads, &d_b, &bc, &d_o, &oc, &tot, 0);
+    if (st == BRX_OK) {
+        KernelTimer t("insert", 0);
+        kmer_scatter_kernel<1><<<grid_for(n_reads, 1, 1 << 20), 256, 0, 0>>>(d_b, d_o, n_reads, set->k, set->d_bits);
+    }
+    hipError_t e = hipDeviceSynchronize();
+    if (d_b)
+        (void)hipFree(d_b);
+    if (d_o)
+        (void)hipFree(d_o);
+    if (st != BRX_OK)
+        return st;
+    if (e != hipSuccess) {
+        set_error("insert kernel: %s", hipGetErrorString(e));
+        return BRX_ERR_HIP;
+    }
+    return BRX_OK;
+}
+
+int brx_set_set(brx_set_t *set, uint64_t forward_kmer, bool value)
+{
+    if (!set)
+        return BRX_ERR_ARG;
+    BRX_TRY(use_device(set->device));
+    const uint64_t h = khash(forward_kmer & kmask(set->k), set->k);
+    set_bit_kernel<<<1, 1>>>(set->d_bits, h, value ? 1 : 0);
+    BRX_HIP(hipDeviceSynchronize());
+    return BRX_OK;
+}
+
+bool brx_set_get(const brx_set_t *set, uint64_t forward_kmer)
+{
+    if (!set || use_device(set->device) != BRX_OK)
+        return false;
+    const uint64_t h = khash(forward_kmer & kmask(set->k), set->k);
+    uint32_t w = 0;
+    if (hipMemcpy(&w, set->d_bits + (h >> 5), 4, hipMemcpyDeviceToHost) != hipSuccess)
+        return false;
+    return (w >> (h & 31u)) & 1u;
+}
+
+int brx_set_get_batch(const brx_set_t *set, const uint64_t *forward_kmers, uint32_t n, uint8_t *out)
+{
+    if (!set || (!forward_kmers && n) || (!out && n))
+        return BRX_ERR_ARG;
+    BRX_TRY(use_device(set->device));
+    if (!n)
+        return BRX_OK;
+    uint64_t *d_k = nullptr;
+    uint8_t *d_o = nullptr;
+    BRX_HIP(hipMalloc((void **)&d_k, (uint64_t)n * 8));
+    hipError_t e = hipMalloc((void **)&d_o, n);
+    if (e != hipSuccess) {
+        (void)hipFree(d_k);
+        set_error("hipMalloc: %s", hipGetErrorString(e));
+        return BRX_ERR_NOMEM;
+    }
+    e = hipMemcpy(d_k, forward_kmers, (uint64_t)n * 8, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        get_kernel<<<(n + 255) / 256, 256>>>(set->d_bits, d_k, n, set->k, d_o);
+        e = hipMemcpy(out, d_o, n, hipMemcpyDeviceToHost);
+    }
+    (void)hipFree(d_k);
+    (void)hipFree(d_o);
+    if (e != hipSuccess) {
+        set_error("get_batch: %s", hipGetErrorString(e));
+        return BRX_ERR_HIP;
+    }
+    return BRX_OK;
+}
+
+uint8_t brx_set_k(const brx_set_t *set) { return set ? (uint8_t)set->k : 0; }
+
+int brx_set_device(const brx_set_t *set) { return set ? set->device : -1; }
+
+int brx_set_export_solid_bytes(const brx_set_t *set, uint8_t *buf, size_t cap, size_t *len)
+{
+    if (!set || !len)
+        return BRX_ERR_ARG;
+    const size_t need = 1 + (size_t)set_nbytes_file(set->k);
+    *len = need;
+    if (!buf || cap < need) {
+        set_error("export needs %zu bytes, buffer has %zu", need, cap);
+        return BRX_ERR_OVERFLOW;
+    }
+    BRX_TRY(use_device(set->device));
+    buf[0] = (uint8_t)set->k;
+    BRX_HIP(hipMemcpy(buf + 1, set->d_bits, need - 1, hipMemcpyDeviceToHost));
+    return BRX_OK;
+}
+
+int brx_set_popcount(const brx_set_t *set, uint64_t *n_set_bits)
+{
+    if (!set || !n_set_bits)
+        return BRX_ERR_ARG;
+    BRX_TRY(use_device(set->device));
+    unsigned long long *d_t = nullptr;
+    BRX_HIP(hipMalloc((void **)&d_t, 8));
+    BRX_HIP(hipMemset(d_t, 0, 8));
+    popcount_kernel<<<grid_for(set->nwords, 256 * 8), 256>>>(set->d_bits, set->nwords, d_t);
+    unsigned long long t = 0;
+    hipError_t e = hipMemcpy(&t, d_t, 8, hipMemcpyDeviceToHost);
+    (void)hipFree(d_t);
+    if (e != hipSuccess) {
+        set_error("popcount: %s", hipGetErrorString(e));
+        return BRX_ERR_HIP;
+    }
+    *n_set_bits = t;
+    return BRX_OK;
+}
+
+int brx_set_device_bits(const brx_set_t *set, void **d_bits, uint64_t *n_bytes)
+{
+    if (!set || !d_bits || !n_bytes)
+        return BRX_ERR_ARG;
+    *d_bits = set->d_bits;
+    *n_bytes = set->nwords * 4;
+    return BRX_OK;
+}
+
+void brx_set_free(brx_set_t *set)
+{
+    if (!set)
+        return;
+    if (set->d_bits && use_device(set->device) == BRX_OK)
+        (void)hipFree(set->d_bits);
+    delete set;
+}
+
+// ---- counting ---------------------------------------------------------------------------------
+
+int brx_set_count_begin(uint8_t k, int device, int strategy, brx_counter_t **out)
+{
+    if (!out)
+        return BRX_ERR_ARG;
+    BRX_TRY(check_k(k, true));
+    BRX_TRY(use_device(device));
+    if (strategy == BRX_COUNT_AUTO)
+        strategy = BRX_COUNT_DENSE;
+    if (strategy != BRX_COUNT_DENSE) {
+        set_error("count strategy %d not implemented", strategy);
+        return BRX_ERR_UNSUPPORTED;
+    }
+    brx_counter *c = new brx_counter();
+    c->k = k;
+    c->device = device;
+    c->strategy = strategy;
+    c->d_counts = nullptr;
+    c->d_keys = nullptr;
+    c->n_keys = c->cap_keys = 0;
+    c->stream = nullptr;
+    c->count_bytes = set_nbits(k) < 32 ? 32 : set_nbits(k); // one u8 per canonical k-mer, >= one output word
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e == hipSuccess)
+        e = hipMalloc((void **)&c->d_counts, c->count_bytes);
+    if (e == hipSuccess) {
+        KernelTimer t("count_zero", c->stream);
+        e = hipMemsetAsync(c->d_counts, 0, c->count_bytes, c->stream);
+    }
+    if (e == hipSuccess)
+        e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) {
+        set_error("counter alloc (%llu B u8 table, k=%d): %s", (unsigned long long)c->count_bytes, (int)k,
+                  hipGetErrorString(e));
+        brx_counter_free(c);
+        return e == hipErrorOutOfMemory ? BRX_ERR_NOMEM : BRX_ERR_HIP;
+    }
+    *out = c;
+    return BRX_OK;
+}
+
+int brx_set_count_add_batch_device(brx_counter_t *c, const uint8_t *d_bases, const uint64_t *d_offsets,
+                                   uint32_t n_reads, uint64_t total_bases, void *stream)
+{
+    (void)total_bases;
+    if (!c || !d_offsets || (!d_bases && n_reads))
+        return BRX_ERR_ARG;
+    BRX_TRY(use_device(c->device));
+    if (!n_reads)
+        return BRX_OK;
+    hipStream_t s = (hipStream_t)stream;
+    {
+        KernelTimer t("count_dense", s);
+        kmer_scatter_kernel<0><<<grid_for(n_reads, 1, 1 << 20), 256, 0, s>>>(d_bases, d_offsets, n_reads, c->k,
+                                                                          c->d_counts);
+    }
+    BRX_HIP(hipGetLastError());
+    return BRX_OK;
+}
+
+int brx_set_count_add_batch(brx_counter_t *c, const uint8_t *bases, const uint64_t *offsets, uint32_t n_reads)
+{
+    if (!c || !offsets || (!bases && n_reads))
+        return BRX_ERR_ARG;
+    BRX_TRY(use_device(c->device));
+    if (!n_reads)
+        return BRX_OK;
+    std::lock_guard<std::mutex> g(c->mu);
+    uint8_t *d_b = nullptr;
+    uint64_t *d_o = nullptr;
+    uint64_t bc = 0, oc = 0, tot = 0;
+    int st = upload_batch(bases, offsets, n_reads, &d_b, &bc, &d_o, &oc, &tot, c->stream);
+    if (st == BRX_OK)
+        st = brx_set_count_add_batch_device(c, d_b, d_o, n_reads, tot, c->stream);
+    hipError_t e = hipStreamSynchronize(c->stream);
+    if (d_b)
+        (void)hipFree(d_b);
+    if (d_o)
+        (void)hipFree(d_o);
+    if (st != BRX_OK)
+        return st;
+    if (e != hipSuccess) {
+        set_error("count kernel: %s", hipGetErrorString(e));
+        return BRX_ERR_HIP;
+    }
+    return BRX_OK;
+}
+
+int brx_set_count_finish(brx_counter_t *c, uint8_t abundance, void *stream, brx_set_t **out)
+{
+    if (!c || !out)
+        return BRX_ERR_ARG;
+    BRX_TRY(use_device(c->device));
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    brx_set *set = nullptr;
+    BRX_TRY(alloc_set(c->k, c->device, false, &set));
+    {
+        KernelTimer t("threshold", s);
+        threshold_kernel<<<grid_for(set->nwords, 256, 256 * 16), 256, 0, s>>>((const uint4 *)c->d_counts, set->nwords,
+                                                                             abundance, set->d_bits);
+    }
+    hipError_t e = hipStreamSynchronize(s);
+    if (e != hipSuccess) {
+        set_error("threshold kernel: %s", hipGetErrorString(e));
+        brx_set_free(set);
+        return BRX_ERR_HIP;
+    }
+    *out = set;
+    return BRX_OK;
+}
+
+int brx_counter_device_counts(brx_counter_t *c, void **d_counts, uint64_t *n_bytes)
+{
+    if (!c || !d_counts || !n_bytes)
+        return BRX_ERR_ARG;
+    if (c->strategy != BRX_COUNT_DENSE) {
+        set_error("counter is not dense");
+        return BRX_ERR_ARG;
+    }
+    *d_counts = c->d_counts;
+    *n_bytes = c->count_bytes;
+    return BRX_OK;
+}
+
+int brx_counter_clamp(brx_counter_t *c, uint8_t cap, void *stream)
+{
+    if (!c || c->strategy != BRX_COUNT_DENSE)
+        return BRX_ERR_ARG;
+    BRX_TRY(use_device(c->device));
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    {
+        KernelTimer t("clamp", s);
+        clamp_kernel<<<grid_for(c->count_bytes / 16, 256, 256 * 16), 256, 0, s>>>((uint4 *)c->d_counts,
+                                                                                c->count_bytes / 16, cap);
+    }
+    BRX_HIP(hipStreamSynchronize(s));
+    return BRX_OK;
+}
+
+int brx_counter_device_keys(brx_counter_t *c, void **d_keys, uint64_t *n_keys)
+{
+    if (!c || !d_keys || !n_keys)
+        return BRX_ERR_ARG;
+    set_error("sorted strategy not implemented");
+    return BRX_ERR_UNSUPPORTED;
+}
+
+int brx_counter_add_keys_device(brx_counter_t *c, const uint64_t *d_keys, uint64_t n_keys, void *stream)
+{
+    (void)c;
+    (void)d_keys;
+    (void)n_keys;
+    (void)stream;
+    set_error("sorted strategy not implemented");
+    return BRX_ERR_UNSUPPORTED;
+}
+
+void brx_counter_free(brx_counter_t *c)
+{
+    if (!c)
+        return;
+    if (use_device(c->device) == BRX_OK) {
+        if (c->d_counts)
+            (void)hipFree(c->d_counts);
+        if (c->d_keys)
+            (void)hipFree(c->d_keys);
+        if (c->stream)
+            (void)hipStreamDestroy(c->stream);
+    }
+    delete c;
+}
+
+} // extern "C"

@@ -1,0 +1,199 @@
+"""br::set mirror: KmerSet trait and the Pcon bitset set, backed by libbrx (HIP).
+
+Reference: src/set.rs:17-23 (trait KmerSet {get, k}, BoxKmerSet), src/set/pcon.rs:13-196
+(Pcon::{new, from_pcon_solid, from_fasta}, get/k), src/main.rs:72-115 (build by counting).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import gzip
+from typing import Iterable, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _lib
+
+
+def pack_reads(reads: Sequence[bytes]) -> Tuple[np.ndarray, np.ndarray]:
+    """records -> (bases uint8[total], offsets uint64[n+1]): the batch layout of include/brx.h."""
+    offs = np.zeros(len(reads) + 1, dtype=np.uint64)
+    if reads:
+        offs[1:] = np.cumsum([len(r) for r in reads], dtype=np.uint64)
+    bases = np.frombuffer(b"".join(reads), dtype=np.uint8) if reads else np.zeros(0, dtype=np.uint8)
+    return np.ascontiguousarray(bases), offs
+
+
+def seq2bit(seq: bytes) -> int:
+    """cocktail::kmer::seq2bit: (ascii >> 1) & 3 per base, first base most significant."""
+    k = 0
+    for c in seq:
+        k = (k << 2) | ((c >> 1) & 3)
+    return k
+
+
+class KmerSet:
+    """trait KmerSet (src/set.rs:17-21)."""
+
+    def get(self, kmer: int) -> bool:  # pragma: no cover - interface
+        raise NotImplementedError
+
+    def k(self) -> int:  # pragma: no cover - interface
+        raise NotImplementedError
+
+
+class Pcon(KmerSet):
+    """set::Pcon: canonical-k-mer bitset resident in HBM (src/set/pcon.rs:13-15)."""
+
+    def __init__(self, handle: int, device: int):
+        self._h = C.c_void_p(handle)
+        self.device = device
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None) and self._h.value:
+                _lib.lib().brx_set_free(self._h)
+                self._h = C.c_void_p(None)
+        except Exception:
+            pass
+
+    # ---- constructors -----------------------------------------------------------------
+    @classmethod
+    def new(cls, k: int, device: int = 0) -> "Pcon":
+        """Pcon::new(pcon::solid::Solid::new(k)) (src/set/pcon.rs:183-185)."""
+        h = C.c_void_p()
+        _lib.check(_lib.lib().brx_set_new(k, device, C.byref(h)))
+        return cls(h.value, device)
+
+    @classmethod
+    def from_pcon_solid(cls, data: bytes, device: int = 0) -> "Pcon":
+        """Pcon::from_pcon_solid (src/set/pcon.rs:18-25).  `data` may be gzip (niffler sniffs
+        compression at src/cli.rs:415) or the raw [k][bits] stream."""
+        if data[:2] == b"\x1f\x8b":
+            data = gzip.decompress(data)
+        buf = np.frombuffer(data, dtype=np.uint8)
+        h = C.c_void_p()
+        _lib.check(_lib.lib().brx_set_new_from_solid_bytes(buf.ctypes.data, buf.size, device, C.byref(h)))
+        return cls(h.value, device)
+
+    @classmethod
+    def from_fasta(cls, reads: Iterable[bytes], k: int, device: int = 0, batch: int = 8192) -> "Pcon":
+        """Pcon::from_fasta (src/set/pcon.rs:47-112): presence-only set of every canonical k-mer."""
+        s = cls.new(k, device)
+        chunk = []
+        for r in reads:
+            chunk.append(r)
+            if len(chunk) == batch:  # populate_buffer(.., 8192), src/set/pcon.rs:82
+                s.insert_reads(chunk)
+                chunk = []
+        if chunk:
+            s.insert_reads(chunk)
+        return s
+
+    @classmethod
+    def from_count(cls, reads: Iterable[bytes], k: int, abundance: int, device: int = 0, batch: int = 8192,
+                   strategy: int = _lib.COUNT_AUTO) -> "Pcon":
+        """`br fasta -k K -a A` (src/main.rs:72-115): count canonical k-mers (u8, saturating),
+        solid iff count > abundance."""
+        c = Counter(k, device, strategy)
+        chunk = []
+        for r in reads:
+            chunk.append(r)
+            if len(chunk) == batch:  # count_fasta(reader, 8192), src/main.rs:74
+                c.add_reads(chunk)
+                chunk = []
+        if chunk:
+            c.add_reads(chunk)
+        return c.finish(abundance)
+
+    # ---- KmerSet ----------------------------------------------------------------------
+    def get(self, kmer: int) -> bool:
+        return bool(_lib.lib().brx_set_get(self._h, kmer))
+
+    def k(self) -> int:
+        return int(_lib.lib().brx_set_k(self._h))
+
+    def get_many(self, kmers: Sequence[int]) -> np.ndarray:
+        km = np.ascontiguousarray(np.asarray(kmers, dtype=np.uint64))
+        out = np.zeros(km.size, dtype=np.uint8)
+        _lib.check(_lib.lib().brx_set_get_batch(self._h, km.ctypes.data, km.size, out.ctypes.data))
+        return out.astype(bool)
+
+    # ---- Solid-level helpers ----------------------------------------------------------
+    def set(self, kmer: int, value: bool = True) -> None:
+        _lib.check(_lib.lib().brx_set_set(self._h, kmer, value))
+
+    def insert_reads(self, reads: Sequence[bytes]) -> None:
+        bases, offs = pack_reads(reads)
+        _lib.check(_lib.lib().brx_set_insert_batch(self._h, bases.ctypes.data, offs.ctypes.data, len(reads)))
+
+    def to_solid_bytes(self) -> bytes:
+        n = C.c_size_t(0)
+        L = _lib.lib()
+        L.brx_set_export_solid_bytes(self._h, None, 0, C.byref(n))
+        buf = np.zeros(n.value, dtype=np.uint8)
+        _lib.check(L.brx_set_export_solid_bytes(self._h, buf.ctypes.data, buf.size, C.byref(n)))
+        return buf.tobytes()
+
+    def export_bits(self) -> np.ndarray:
+        """the packed Lsb0 bit array (without the k byte) as uint8[]."""
+        n = C.c_size_t(0)
+        L = _lib.lib()
+        L.brx_set_export_solid_bytes(self._h, None, 0, C.byref(n))
+        buf = np.zeros(n.value, dtype=np.uint8)
+        _lib.check(L.brx_set_export_solid_bytes(self._h, buf.ctypes.data, buf.size, C.byref(n)))
+        return buf[1:]
+
+    def popcount(self) -> int:
+        n = C.c_uint64(0)
+        _lib.check(_lib.lib().brx_set_popcount(self._h, C.byref(n)))
+        return n.value
+
+    def device_bits(self) -> Tuple[int, int]:
+        p, n = C.c_void_p(), C.c_uint64(0)
+        _lib.check(_lib.lib().brx_set_device_bits(self._h, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+
+class Counter:
+    """pcon::counter::Counter<u8> as used by `br fasta` (src/main.rs:73-78)."""
+
+    def __init__(self, k: int, device: int = 0, strategy: int = _lib.COUNT_AUTO):
+        self._h = C.c_void_p()
+        self.k = k
+        self.device = device
+        _lib.check(_lib.lib().brx_set_count_begin(k, device, strategy, C.byref(self._h)))
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None) and self._h.value:
+                _lib.lib().brx_counter_free(self._h)
+                self._h = C.c_void_p(None)
+        except Exception:
+            pass
+
+    def add_reads(self, reads: Sequence[bytes]) -> None:
+        bases, offs = pack_reads(reads)
+        self.add_batch(bases, offs)
+
+    def add_batch(self, bases: np.ndarray, offsets: np.ndarray) -> None:
+        _lib.check(_lib.lib().brx_set_count_add_batch(self._h, bases.ctypes.data, offsets.ctypes.data,
+                                                      offsets.size - 1))
+
+    def add_batch_device(self, d_bases: int, d_offsets: int, n_reads: int, total_bases: int,
+                         stream: Optional[int] = None) -> None:
+        _lib.check(_lib.lib().brx_set_count_add_batch_device(self._h, d_bases, d_offsets, n_reads, total_bases,
+                                                             stream))
+
+    def clamp(self, cap: int, stream: Optional[int] = None) -> None:
+        _lib.check(_lib.lib().brx_counter_clamp(self._h, cap, stream))
+
+    def device_counts(self) -> Tuple[int, int]:
+        p, n = C.c_void_p(), C.c_uint64(0)
+        _lib.check(_lib.lib().brx_counter_device_counts(self._h, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def finish(self, abundance: int, stream: Optional[int] = None) -> Pcon:
+        """Solid::from_count(k, counts, abundance): solid iff count > abundance."""
+        h = C.c_void_p()
+        _lib.check(_lib.lib().brx_set_count_finish(self._h, abundance, stream, C.byref(h)))
+        return Pcon(h.value, self.device)

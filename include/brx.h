@@ -1,0 +1,172 @@
+/*
+ * brx.h -- C ABI of the MI355X-native replacement for natir/br's hot path:
+ * solid-k-mer set build (count -> threshold -> packed canonical bitset) and the
+ * per-read correction scan (br::correct::{One,Two,Graph,Greedy,GapSize} against
+ * br::set::KmerSet).
+ *
+ * The reference (Rust, /root/reference) has no FFI layer; its seam is two traits
+ * and two free functions.  Each entry point below names the reference interface it
+ * replaces (file:line under /root/reference).  INTEGRATION.md shows the Rust-side
+ * binding (`impl KmerSet for HipSet`, `run_correction` calling the batch entry).
+ *
+ * Conventions
+ *   - every function returns 0 (BRX_OK) or a negative brx_status; nothing unwinds;
+ *     brx_last_error() gives a thread-local message for the last failure.
+ *   - "bases/offsets" batches: reads concatenated as ASCII bytes, read r =
+ *     bases[offsets[r] .. offsets[r+1]); offsets has n_reads+1 entries.
+ *   - k-mers are FORWARD 2-bit k-mers (A=0 C=1 T=2 G=3, first base most
+ *     significant, 2k low bits) exactly as `KmerSet::get` receives them; the
+ *     library canonicalises (even-popcount member of {kmer, revcomp}) and indexes
+ *     bit (canonical >> 1), like pcon::solid::Solid.
+ *   - `_device` variants take device pointers (HIP, same device as the handle) and a
+ *     hipStream_t passed as void*; the plain variants take host pointers and do the
+ *     transfers themselves.
+ *   - a brx_set_t is immutable once built/loaded and may be shared by any number of
+ *     chains; a brx_chain_t owns its workspace and serialises concurrent calls.
+ *   - there is NO CPU fallback: without a usable gfx950 device every compute entry
+ *     returns BRX_ERR_NODEVICE.
+ */
+#ifndef BRX_H
+#define BRX_H
+
+#include <stdbool.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct brx_set brx_set_t;         /* Box<dyn KmerSet> backed by set::Pcon   src/set.rs:17-23, src/set/pcon.rs:13-15 */
+typedef struct brx_counter brx_counter_t; /* pcon::counter::Counter<u8>             src/main.rs:73-78 */
+typedef struct brx_chain brx_chain_t;     /* Vec<Box<dyn Corrector>> of build_methods  src/lib.rs:141-164 */
+
+typedef enum brx_status {
+    BRX_OK = 0,
+    BRX_ERR_ARG = -1,         /* bad argument (k even/out of range, null pointer, ...) */
+    BRX_ERR_NOMEM = -2,       /* host or device allocation failed                      */
+    BRX_ERR_HIP = -3,         /* a HIP runtime call failed                             */
+    BRX_ERR_NODEVICE = -4,    /* no usable GPU: the product path has no CPU fallback   */
+    BRX_ERR_FORMAT = -5,      /* malformed .solid stream (error.rs: wraps pcon errors) */
+    BRX_ERR_UNSUPPORTED = -6, /* valid in the reference, not yet implemented here      */
+    BRX_ERR_OVERFLOW = -7     /* caller-provided output buffer too small               */
+} brx_status;
+
+/* CorrectionMethod, src/cli.rs:11-17; order = build_methods' match, src/lib.rs:150-160 */
+enum { BRX_ONE = 0, BRX_TWO = 1, BRX_GRAPH = 2, BRX_GREEDY = 3, BRX_GAP_SIZE = 4 };
+
+/* one entry of the method list handed to build_methods (src/lib.rs:141-146):
+ * confirm = -C (default 5, src/cli.rs:135-137), max_search = -M (default 7, :140-142) */
+typedef struct brx_method {
+    uint8_t method;
+    uint8_t confirm;
+    uint8_t max_search;
+} brx_method_t;
+
+/* ---- diagnostics -------------------------------------------------------------------- */
+const char *brx_strerror(int status);
+const char *brx_last_error(void);
+int brx_version(void);
+int brx_device_count(int *n); /* BRX_OK and *n == 0 when no GPU is visible */
+
+/* per-kernel HIP-event timers (events recorded on the launch stream).  Names:
+ * "count_dense", "threshold", "correct_pass", "compact", ...          */
+int brx_profile_enable(int on);
+int brx_profile_reset(void);
+int brx_profile_get(const char *kernel, double *total_ms, uint64_t *launches);
+int brx_profile_names(char *buf, size_t cap); /* comma-separated list of timer names */
+
+/* ---- KmerSet: src/set.rs:17-21 --------------------------------------------------------- */
+/* Pcon::new(Solid::new(k)): empty set                              src/set/pcon.rs:183-185 */
+int brx_set_new(uint8_t k, int device, brx_set_t **out);
+/* Pcon::from_pcon_solid: [k:u8][bits Lsb0], already decompressed   src/set/pcon.rs:18-25   */
+int brx_set_new_from_solid_bytes(const uint8_t *buf, size_t len, int device, brx_set_t **out);
+/* Pcon::from_fasta (presence only): OR in every canonical k-mer of every read of length >= k
+ *                                                                  src/set/pcon.rs:47-112  */
+int brx_set_insert_batch(brx_set_t *set, const uint8_t *bases, const uint64_t *offsets, uint32_t n_reads);
+/* Solid::set(kmer, value) -- host-side slow path (tests, csv input) src/set/pcon.rs:38      */
+int brx_set_set(brx_set_t *set, uint64_t forward_kmer, bool value);
+/* KmerSet::get                                                     src/set/pcon.rs:189-191 */
+bool brx_set_get(const brx_set_t *set, uint64_t forward_kmer);
+/* n independent KmerSet::get calls in one launch; out[i] = 0/1 */
+int brx_set_get_batch(const brx_set_t *set, const uint64_t *forward_kmers, uint32_t n, uint8_t *out);
+/* KmerSet::k                                                       src/set/pcon.rs:193-195 */
+uint8_t brx_set_k(const brx_set_t *set);
+int brx_set_device(const brx_set_t *set);
+/* .solid writer ([k][bits]); len = 1 + 2^(2k-4) (at least 2)                               */
+int brx_set_export_solid_bytes(const brx_set_t *set, uint8_t *buf, size_t cap, size_t *len);
+int brx_set_popcount(const brx_set_t *set, uint64_t *n_set_bits);
+/* device view of the packed bit array (for RCCL all-gather / OR across ranks)              */
+int brx_set_device_bits(const brx_set_t *set, void **d_bits, uint64_t *n_bytes);
+void brx_set_free(brx_set_t *set);
+
+/* ---- set build by counting: src/main.rs:72-115 -------------------------------------------
+ * Counter::<u8>::new(k) -> count_fasta -> Solid::from_count(k, counts, abundance).
+ * k must be odd (Fasta::kmer_size forces it, src/cli.rs:277-279) and <= 31.
+ * strategy: BRX_COUNT_DENSE keeps the reference's 2^(2k-1)-byte u8 table in HBM;
+ * BRX_COUNT_SORTED keeps the canonical hashes and sorts them (same bitset, no table).     */
+enum { BRX_COUNT_AUTO = 0, BRX_COUNT_DENSE = 1, BRX_COUNT_SORTED = 2 };
+int brx_set_count_begin(uint8_t k, int device, int strategy, brx_counter_t **out);
+int brx_set_count_add_batch(brx_counter_t *c, const uint8_t *bases, const uint64_t *offsets, uint32_t n_reads);
+int brx_set_count_add_batch_device(brx_counter_t *c, const uint8_t *d_bases, const uint64_t *d_offsets,
+                                   uint32_t n_reads, uint64_t total_bases, void *stream);
+/* solid iff count > abundance (strict; pinned by tests/data/raw.k11.a2.solid).  The counter
+ * stays valid (finish may be called again with another abundance) until freed.             */
+int brx_set_count_finish(brx_counter_t *c, uint8_t abundance, void *stream, brx_set_t **out);
+/* dense strategy only: device view of the u8 table, for the RCCL reduction of SURVEY 8(e)   */
+int brx_counter_device_counts(brx_counter_t *c, void **d_counts, uint64_t *n_bytes);
+/* clamp every count to min(count, cap) in place (the exact-sum trick before an u8 all-reduce) */
+int brx_counter_clamp(brx_counter_t *c, uint8_t cap, void *stream);
+/* sorted strategy only: device view of the (unsorted) canonical-hash list gathered so far   */
+int brx_counter_device_keys(brx_counter_t *c, void **d_keys, uint64_t *n_keys);
+/* sorted strategy: append hashes produced elsewhere (e.g. received from another rank)       */
+int brx_counter_add_keys_device(brx_counter_t *c, const uint64_t *d_keys, uint64_t n_keys, void *stream);
+void brx_counter_free(brx_counter_t *c);
+
+/* ---- correction: src/lib.rs:22-139 (run_correction) + src/correct/mod.rs:44-108 ----------
+ * brx_chain_new = build_methods (order kept, duplicates allowed).  two_side=true means the
+ * -s flag was given, i.e. the reverse pass is SKIPPED (src/lib.rs:48,110).                  */
+int brx_chain_new(const brx_set_t *set, const brx_method_t *methods, uint32_t n_methods, bool two_side,
+                  brx_chain_t **out);
+/* one batch of records through the whole per-record body of run_correction
+ * (src/lib.rs:42-55): every method in order, then (unless two_side) reverse, every method,
+ * reverse back.  Output in input order.  *out_bases / *out_offsets are malloc'd by the
+ * library; release with brx_buf_free.                                                       */
+int brx_chain_correct_batch(brx_chain_t *chain, const uint8_t *bases, const uint64_t *offsets, uint32_t n_reads,
+                            uint8_t **out_bases, uint64_t **out_offsets);
+/* same on device buffers: d_out (capacity out_cap bytes) and d_out_offsets (n_reads+1) are
+ * caller-allocated; *out_total receives the number of corrected bytes.  Returns
+ * BRX_ERR_OVERFLOW (with *out_total = needed) if out_cap is too small.  The call returns
+ * after its kernels have completed on `stream`.                                            */
+int brx_chain_correct_batch_device(brx_chain_t *chain, const uint8_t *d_bases, const uint64_t *d_offsets,
+                                   uint32_t n_reads, uint64_t total_bases, uint8_t *d_out, uint64_t out_cap,
+                                   uint64_t *d_out_offsets, uint64_t *out_total, void *stream);
+/* counters of the last batch: [0] scan rounds, [1] probes issued, [2] triggers, [3] fixes,
+ * [4] overflow retries (u64[8], rest reserved)                                             */
+int brx_chain_last_stats(const brx_chain_t *chain, uint64_t *stats8);
+void brx_chain_free(brx_chain_t *chain);
+void brx_buf_free(void *p);
+
+/* ---- synthetic reads: deterministic, identical on host and device ----------
+ * genome: i.i.d. uniform ACGT of length genome_len (seed); read r: window of read_len
+ * reference bases at a uniform start, strand +/- with p=1/2, per-reference-base errors
+ * sub/ins/del at the given rates (parts per 10 000).  Output offsets are fixed-stride
+ * capacity slots compacted by the call; *total receives the number of bases.               */
+typedef struct brx_synth {
+    uint64_t seed;
+    uint64_t genome_len;
+    uint32_t read_len;
+    uint32_t sub_e4, ins_e4, del_e4;
+} brx_synth_t;
+int brx_synth_genome_device(const brx_synth_t *cfg, int device, uint8_t *d_genome, void *stream);
+int brx_synth_reads_device(const brx_synth_t *cfg, int device, const uint8_t *d_genome, uint64_t first_read,
+                           uint32_t n_reads, uint8_t *d_bases, uint64_t bases_cap, uint64_t *d_offsets,
+                           uint64_t *total, void *stream);
+int brx_synth_genome_host(const brx_synth_t *cfg, uint8_t *genome);
+int brx_synth_reads_host(const brx_synth_t *cfg, const uint8_t *genome, uint64_t first_read, uint32_t n_reads,
+                         uint8_t *bases, uint64_t bases_cap, uint64_t *offsets, uint64_t *total);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BRX_H */

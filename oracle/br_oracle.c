@@ -196,8 +196,6 @@ typedef struct {
     int k;
     uint64_t nbits;
     uint8_t *bits;
-    /* statistics for regression fixtures */
-    uint64_t n_get;
 } bro_solid;
 
 uint64_t bro_solid_nbytes(int k)
@@ -249,7 +247,6 @@ void bro_solid_set(bro_solid *s, uint64_t kmer, int val)
 int bro_solid_get(const bro_solid *s, uint64_t kmer)
 {
     uint64_t h = bro_hash(kmer, s->k);
-    ((bro_solid *)s)->n_get++;
     return (s->bits[h >> 3] >> (h & 7)) & 1;
 }
 

@@ -1,0 +1,300 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle, on a real MI355X.
+
+Bit-exact everywhere: this is integer/byte work.  Sizes are chosen so the oracle finishes in
+seconds; full-size cases use size-independent properties (see test_gpu_scale.py).
+"""
+import gzip
+import os
+
+import numpy as np
+import pytest
+
+import br_amd
+from br_amd import _lib, synth
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+IMPLEMENTED = {"one"}  # methods with a GPU kernel so far; the others must fail loudly
+
+
+def _oracle_set(v):
+    s = O.Solid(v["k"])
+    for q in v["set_seqs"]:
+        s.set_seq(q.encode())
+    for q in v["set_kmers"]:
+        s.set(O.seq2bit(q.encode()))
+    return s
+
+
+def _gpu_set_from_oracle(s):
+    return br_amd.Pcon.from_pcon_solid(s.to_bytes())
+
+
+def _corrector(gs, v):
+    m = v["method"]
+    if m == "one":
+        return br_amd.One(gs, v["confirm"])
+    if m == "two":
+        return br_amd.Two(gs, v["confirm"])
+    if m == "graph":
+        return br_amd.Graph(gs)
+    if m == "greedy":
+        return br_amd.Greedy(gs, v["max_search"], v["confirm"])
+    return br_amd.GapSize(gs, v["confirm"])
+
+
+# ---------------------------------------------------------------- set ---------------------------
+def test_device_present():
+    assert _lib.device_count() >= 1
+
+
+def test_solid_roundtrip(solid_fixture_bytes):
+    gs = br_amd.Pcon.from_pcon_solid(solid_fixture_bytes)
+    assert gs.k() == 11
+    assert gs.to_solid_bytes() == solid_fixture_bytes
+    assert gs.popcount() == 123072
+    # gzip'ed stream, as the reference's fixture is stored
+    gz = br_amd.Pcon.from_pcon_solid(gzip.compress(solid_fixture_bytes))
+    assert gz.to_solid_bytes() == solid_fixture_bytes
+    with pytest.raises(_lib.BrxError):
+        br_amd.Pcon.from_pcon_solid(solid_fixture_bytes[:-1])
+
+
+def test_get_matches_oracle(solid_fixture_bytes):
+    gs = br_amd.Pcon.from_pcon_solid(solid_fixture_bytes)
+    os_ = O.Solid.from_bytes(solid_fixture_bytes)
+    rng = np.random.default_rng(1)
+    kmers = rng.integers(0, 4 ** 11, size=20000, dtype=np.uint64)
+    got = gs.get_many(kmers)
+    exp = np.array([os_.get(int(x)) for x in kmers])
+    assert np.array_equal(got, exp)
+    for x in kmers[:50]:
+        assert gs.get(int(x)) == os_.get(int(x))
+    assert not br_amd.Pcon.new(11).get(0)           # src/set/pcon.rs:239-241 (absence)
+
+
+def test_pcon_set_vectors(unit_vectors):
+    d = unit_vectors["set"]["pcon"]
+    k, seq = d["k"], d["seq"].encode()
+    gs = br_amd.Pcon.from_fasta([seq], k)
+    fw = [O.seq2bit(seq[i:i + k]) for i in range(len(seq) - k + 1)]
+    assert gs.get_many(fw).all()                                     # forward
+    assert gs.get_many([O.canonical(x, k) for x in fw]).all()        # canonical
+    assert gs.get_many([O.revcomp(x, k) for x in fw]).all()
+    assert not gs.get(d["absent_kmer"])
+    assert gs.k() == k
+    ref = O.Solid(k)
+    ref.set_seq(seq)
+    assert gs.to_solid_bytes() == ref.to_bytes()
+
+
+def test_set_and_found_alt_kmer(unit_vectors):
+    d = unit_vectors["set"]["found_alt_kmer"]
+    gs = br_amd.Pcon.new(d["k"])
+    for q in d["set_kmers"]:
+        gs.set(br_amd.seq2bit(q.encode()))
+    base = br_amd.seq2bit(d["query"].encode()) >> 2
+    alts = [a for a in range(4) if gs.get((base << 2) | a)]
+    assert alts == d["alt_nucs"]
+    gs.set(br_amd.seq2bit(d["set_kmers"][0].encode()), False)
+    assert not gs.get(br_amd.seq2bit(d["set_kmers"][0].encode()))
+
+
+def test_set_build_kat(raw_reads, solid_fixture_bytes):
+    """raw.fasta, k=11, count > 2  ==  tests/data/raw.k11.a2.solid, bit for bit."""
+    gs = br_amd.Pcon.from_count(raw_reads, 11, 2)
+    assert gs.to_solid_bytes() == solid_fixture_bytes
+    # batching must not matter (count_fasta(reader, 8192))
+    gs2 = br_amd.Pcon.from_count(raw_reads, 11, 2, batch=7)
+    assert gs2.to_solid_bytes() == solid_fixture_bytes
+
+
+@pytest.mark.parametrize("k,abundance", [(5, 0), (9, 1), (13, 3), (15, 2)])
+def test_set_build_vs_oracle(raw_reads, k, abundance):
+    reads = raw_reads[:40] + [b"", b"ACG", b"N" * 40, b"acgtacgtacgtacgtacgtacgt"]
+    gs = br_amd.Pcon.from_count(reads, k, abundance)
+    ref = O.Solid.from_count(k, O.count_reads(k, reads), abundance)
+    assert gs.to_solid_bytes() == ref.to_bytes()
+
+
+def test_counter_saturates_at_255():
+    k = 5
+    reads = [b"A" * (k + 299)] * 3 + [b"ACGTACGTAC"]      # AAAAA seen 900 times
+    for a in (0, 200, 254):
+        gs = br_amd.Pcon.from_count(reads, k, a)
+        ref = O.Solid.from_count(k, O.count_reads(k, reads), a)
+        assert gs.to_solid_bytes() == ref.to_bytes()
+        assert gs.get(0)
+    assert not br_amd.Pcon.from_count(reads, k, 255).get(0)   # nothing exceeds 255
+
+
+def test_presence_build_vs_oracle(raw_reads):
+    k = 13
+    reads = raw_reads[:25]
+    gs = br_amd.Pcon.from_fasta(reads, k)
+    ref = O.Solid(k)
+    for r in reads:
+        ref.set_seq(r)
+    assert gs.to_solid_bytes() == ref.to_bytes()
+
+
+def test_even_k_rejected_for_build():
+    with pytest.raises(_lib.BrxError):
+        br_amd.Counter(12)
+
+
+# ---------------------------------------------------------------- correction ---------------------
+def test_unit_vectors_on_gpu(unit_vectors):
+    """the reference's own corrector tests, run through the HIP path."""
+    ran = 0
+    for v in unit_vectors["vectors"]:
+        if v["ignored"]:
+            continue
+        gs = _gpu_set_from_oracle(_oracle_set(v))
+        if v["method"] not in IMPLEMENTED:
+            with pytest.raises(_lib.BrxError) as e:
+                _corrector(gs, v).correct(v["cases"][0][0].encode())
+            assert e.value.status == _lib.BRX_ERR_UNSUPPORTED
+            continue
+        c = _corrector(gs, v)
+        for a, b in v["cases"]:
+            assert c.correct(a.encode()).decode() == b, v["name"]
+            ran += 1
+    assert ran >= 17
+
+
+@pytest.mark.parametrize("group", ["16", "32", "64"])
+def test_one_raw_fasta_fixture_set(raw_reads, solid_fixture_bytes, group, monkeypatch):
+    """the reference's `solid` integration config (tests/br.rs:35-59): raw.fasta corrected with
+    raw.k11.a2.solid, method One, c=5, forward + reverse pass; byte-identical to the oracle."""
+    monkeypatch.setenv("BRX_GROUP", group)
+    gs = br_amd.Pcon.from_pcon_solid(solid_fixture_bytes)
+    os_ = O.Solid.from_bytes(solid_fixture_bytes)
+    om = O.build_methods(os_, ["one"], 5, 7)
+    for two_side in (False, True):
+        chain = br_amd.Chain(gs, [("one", 5, 7)], two_side=two_side)
+        got = chain.correct_reads(raw_reads)
+        for r, g in zip(raw_reads, got):
+            assert g == O.correct_record(om, r, two_side)
+    if group == "16":
+        st = chain.last_stats()
+        assert st["probes"] > 0 and st["rounds"] > 0
+
+
+def test_one_chained_methods(raw_reads, solid_fixture_bytes):
+    """method chaining: the output of one corrector feeds the next (src/lib.rs:44-46)."""
+    gs = br_amd.Pcon.from_pcon_solid(solid_fixture_bytes)
+    os_ = O.Solid.from_bytes(solid_fixture_bytes)
+    reads = raw_reads[:60]
+    spec = [("one", 5, 7), ("one", 2, 7), ("one", 9, 7)]
+    om = [O.Corrector(os_, m, c, ms) for m, c, ms in spec]
+    got = br_amd.Chain(gs, spec, two_side=False).correct_reads(reads)
+    for r, g in zip(reads, got):
+        assert g == O.correct_record(om, r, False)
+
+
+def test_edge_reads(solid_fixture_bytes):
+    gs = br_amd.Pcon.from_pcon_solid(solid_fixture_bytes)
+    os_ = O.Solid.from_bytes(solid_fixture_bytes)
+    om = O.build_methods(os_, ["one"], 5, 7)
+    chain = br_amd.Chain(gs, [("one", 5, 7)], two_side=False)
+    assert chain.correct_reads([]) == []
+    reads = [b"", b"A", b"ACGTACGTAC", b"ACGTACGTACG", b"ACGTACGTACGT", b"acgtnACGTNNxyzACGTACGTTTGACCA",
+             b"N" * 300, b"ACGT" * 100]
+    got = chain.correct_reads(reads)
+    for r, g in zip(reads, got):
+        assert g == O.correct_record(om, r, False)
+
+
+def test_large_confirm(raw_reads, solid_fixture_bytes):
+    gs = br_amd.Pcon.from_pcon_solid(solid_fixture_bytes)
+    os_ = O.Solid.from_bytes(solid_fixture_bytes)
+    reads = raw_reads[:30]
+    for c in (1, 12, 40):
+        om = O.build_methods(os_, ["one"], c, 7)
+        got = br_amd.Chain(gs, [("one", c, 7)], two_side=False).correct_reads(reads)
+        for r, g in zip(reads, got):
+            assert g == O.correct_record(om, r, False), c
+
+
+def test_run_correction_end_to_end(tmp_path, golden_dir, solid_fixture_bytes):
+    """br -i raw.fasta -o corr.fasta -c one solid -i raw.k11.a2.solid -f solid, via the python mirror."""
+    gs = br_amd.Pcon.from_pcon_solid(open(os.path.join(golden_dir, "raw.k11.a2.solid"), "rb").read())
+    methods = br_amd.build_methods(["one"], gs, 5, 7)
+    out_path = tmp_path / "corr.fasta"
+    with open(os.path.join(golden_dir, "raw.fasta"), "rb") as fi, open(out_path, "wb") as fo:
+        br_amd.run_correction([fi], [fo], methods, two_side=False)
+    from br_amd import fasta
+    os_ = O.Solid.from_bytes(solid_fixture_bytes)
+    om = O.build_methods(os_, ["one"], 5, 7)
+    with open(os.path.join(golden_dir, "raw.fasta"), "rb") as fi, open(out_path, "rb") as fo:
+        src = list(fasta.read_records(fi))
+        got = list(fasta.read_records(fo))
+    assert len(src) == len(got) == 206
+    total = 0
+    for (n0, d0, s0), (n1, d1, s1) in zip(src, got):
+        assert (n0, d0) == (n1, d1)
+        assert s1 == O.correct_record(om, s0, False)
+        total += len(s1)
+    assert total == 2520330
+
+
+# ---------------------------------------------------------------- synthetic -----------------------
+def _torch():
+    import torch
+    return torch
+
+
+def test_synth_device_equals_host():
+    torch = _torch()
+    cfg = synth.config(genome_len=300_000, read_len=3_000)
+    g = synth.genome_host(cfg)
+    hb, ho = synth.reads_host(cfg, g, 5, 200)
+    dg = torch.empty(cfg.genome_len, dtype=torch.uint8, device="cuda")
+    synth.genome_device(cfg, 0, dg.data_ptr())
+    assert np.array_equal(dg.cpu().numpy(), g)
+    db = torch.empty(200 * 7000, dtype=torch.uint8, device="cuda")
+    do = torch.empty(201, dtype=torch.int64, device="cuda")
+    tot = synth.reads_device(cfg, 0, dg.data_ptr(), 5, 200, db.data_ptr(), db.numel(), do.data_ptr())
+    assert tot == hb.size
+    assert np.array_equal(do.cpu().numpy().astype(np.uint64), ho)
+    assert np.array_equal(db[:tot].cpu().numpy(), hb)
+
+
+@pytest.mark.parametrize("k", [13, 15])
+def test_synthetic_build_and_correct(k):
+    """small synthetic job end to end on device buffers: count -> threshold -> One fwd+rev."""
+    torch = _torch()
+    n_reads, read_len = 400, 2_000
+    cfg = synth.config(genome_len=n_reads * read_len // 25, read_len=read_len)
+    g = synth.genome_host(cfg)
+    hb, ho = synth.reads_host(cfg, g, 0, n_reads)
+    reads = [hb[int(ho[i]):int(ho[i + 1])].tobytes() for i in range(n_reads)]
+
+    dg = torch.from_numpy(g).cuda()
+    db = torch.empty(n_reads * (2 * read_len + 8), dtype=torch.uint8, device="cuda")
+    do = torch.empty(n_reads + 1, dtype=torch.int64, device="cuda")
+    tot = synth.reads_device(cfg, 0, dg.data_ptr(), 0, n_reads, db.data_ptr(), db.numel(), do.data_ptr())
+    stream = torch.cuda.current_stream().cuda_stream
+
+    cnt = br_amd.Counter(k)
+    cnt.add_batch_device(db.data_ptr(), do.data_ptr(), n_reads, tot, stream)
+    gs = cnt.finish(3, stream)
+    ref = O.Solid.from_count(k, O.count_reads(k, reads), 3)
+    assert gs.to_solid_bytes() == ref.to_bytes()
+    assert gs.popcount() > 0
+
+    chain = br_amd.Chain(gs, [("one", 5, 7)], two_side=False)
+    d_out = torch.empty(int(tot * 1.1) + 4096, dtype=torch.uint8, device="cuda")
+    d_oo = torch.empty(n_reads + 1, dtype=torch.int64, device="cuda")
+    total = chain.correct_batch_device(db.data_ptr(), do.data_ptr(), n_reads, tot, d_out.data_ptr(), d_out.numel(),
+                                       d_oo.data_ptr(), stream)
+    out = d_out[:total].cpu().numpy()
+    oo = d_oo.cpu().numpy()
+    om = O.build_methods(ref, ["one"], 5, 7)
+    exp, exp_o = O.correct_batch(om, hb, ho, False)
+    assert np.array_equal(oo.astype(np.uint64), exp_o)
+    assert np.array_equal(out, exp)
+    st = chain.last_stats()
+    assert st["fixes"] > 0 and st["triggers"] >= st["fixes"]
