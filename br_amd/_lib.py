@@ -64,6 +64,8 @@ SIGNATURES = {
     "brx_set_count_add_batch": (C.c_int, [_vp, _vp, _vp, C.c_uint32]),
     "brx_set_count_add_batch_device": (C.c_int, [_vp, _vp, _vp, C.c_uint32, C.c_uint64, _vp]),
     "brx_set_count_finish": (C.c_int, [_vp, C.c_uint8, _vp, _pp]),
+    "brx_set_count_finish_into": (C.c_int, [_vp, C.c_uint8, _vp, _vp]),
+    "brx_counter_reset": (C.c_int, [_vp, _vp]),
     "brx_counter_device_counts": (C.c_int, [_vp, _pp, _u64p]),
     "brx_counter_clamp": (C.c_int, [_vp, C.c_uint8, _vp]),
     "brx_counter_device_keys": (C.c_int, [_vp, _pp, _u64p]),
@@ -86,11 +88,28 @@ SIGNATURES = {
 _lib = None
 
 
+def _adopt_torch_runtime() -> None:
+    """One HIP runtime per process.  PyTorch wheels bundle their own libamdhip64.so.7 (+ HSA
+    runtime); libbrx.so needs `libamdhip64.so.7` by soname.  If libbrx is loaded first it pulls
+    /opt/rocm's copy, torch later loads its bundled copy next to it, and the second runtime in
+    the process sees no GPU.  Importing torch first makes the loader resolve libbrx's dependency
+    to the copy torch already mapped.  A host that never uses torch in-process (a Rust/C++
+    caller of the C ABI, or BRX_NO_TORCH=1) simply gets /opt/rocm's runtime via RUNPATH."""
+    import sys
+    if "torch" in sys.modules or os.environ.get("BRX_NO_TORCH") == "1":
+        return
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
+
+
 def lib():
     """Load libbrx.so.  Raises (loudly) if the HIP library has not been built."""
     global _lib
     if _lib is not None:
         return _lib
+    _adopt_torch_runtime()
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             f"{LIB_PATH} not found: build it with `make -C br_amd/csrc` (or __graft_entry__.build()). "

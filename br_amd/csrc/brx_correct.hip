@@ -515,7 +515,7 @@ int brx_chain_correct_batch_device(brx_chain_t *ch, const uint8_t *d_bases, cons
     }
     BRX_TRY(use_device(ch->device));
     std::lock_guard<std::mutex> g(ch->mu);
-    hipStream_t s = stream ? (hipStream_t)stream : ch->stream;
+    hipStream_t s = (hipStream_t)stream; // nullptr = the legacy default stream
     *out_total = 0;
     if (n_reads == 0) {
         BRX_HIP(hipMemsetAsync(d_out_offsets, 0, 8, s));

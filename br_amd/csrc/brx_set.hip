@@ -513,24 +513,57 @@ int brx_set_count_add_batch(brx_counter_t *c, const uint8_t *bases, const uint64
     return BRX_OK;
 }
 
+int brx_counter_reset(brx_counter_t *c, void *stream)
+{
+    if (!c)
+        return BRX_ERR_ARG;
+    BRX_TRY(use_device(c->device));
+    hipStream_t s = (hipStream_t)stream;
+    if (c->d_counts) {
+        KernelTimer t("count_zero", s);
+        BRX_HIP(hipMemsetAsync(c->d_counts, 0, c->count_bytes, s));
+    }
+    c->n_keys = 0;
+    return BRX_OK;
+}
+
+int brx_set_count_finish_into(brx_counter_t *c, uint8_t abundance, void *stream, brx_set_t *dst)
+{
+    if (!c || !dst)
+        return BRX_ERR_ARG;
+    if (dst->k != c->k || dst->device != c->device) {
+        set_error("finish_into: destination set has k=%d device=%d, counter has k=%d device=%d", dst->k, dst->device,
+                  c->k, c->device);
+        return BRX_ERR_ARG;
+    }
+    BRX_TRY(use_device(c->device));
+    hipStream_t s = (hipStream_t)stream; // nullptr = the legacy default stream, like any HIP API
+    {
+        KernelTimer t("threshold", s);
+        threshold_kernel<<<grid_for(dst->nwords, 256, 256 * 16), 256, 0, s>>>((const uint4 *)c->d_counts, dst->nwords,
+                                                                             abundance, dst->d_bits);
+    }
+    BRX_HIP(hipGetLastError());
+    return BRX_OK;
+}
+
 int brx_set_count_finish(brx_counter_t *c, uint8_t abundance, void *stream, brx_set_t **out)
 {
     if (!c || !out)
         return BRX_ERR_ARG;
-    BRX_TRY(use_device(c->device));
-    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
     brx_set *set = nullptr;
     BRX_TRY(alloc_set(c->k, c->device, false, &set));
-    {
-        KernelTimer t("threshold", s);
-        threshold_kernel<<<grid_for(set->nwords, 256, 256 * 16), 256, 0, s>>>((const uint4 *)c->d_counts, set->nwords,
-                                                                             abundance, set->d_bits);
+    int st = brx_set_count_finish_into(c, abundance, stream, set);
+    if (st == BRX_OK) {
+        hipError_t e = hipStreamSynchronize((hipStream_t)stream);
+        if (e != hipSuccess) {
+            set_error("threshold kernel: %s", hipGetErrorString(e));
+            st = BRX_ERR_HIP;
+        }
     }
-    hipError_t e = hipStreamSynchronize(s);
-    if (e != hipSuccess) {
-        set_error("threshold kernel: %s", hipGetErrorString(e));
+    if (st != BRX_OK) {
         brx_set_free(set);
-        return BRX_ERR_HIP;
+        return st;
     }
     *out = set;
     return BRX_OK;
@@ -554,7 +587,7 @@ int brx_counter_clamp(brx_counter_t *c, uint8_t cap, void *stream)
     if (!c || c->strategy != BRX_COUNT_DENSE)
         return BRX_ERR_ARG;
     BRX_TRY(use_device(c->device));
-    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    hipStream_t s = (hipStream_t)stream; // nullptr = the legacy default stream, like any HIP API
     {
         KernelTimer t("clamp", s);
         clamp_kernel<<<grid_for(c->count_bytes / 16, 256, 256 * 16), 256, 0, s>>>((uint4 *)c->d_counts,

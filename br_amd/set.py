@@ -192,6 +192,12 @@ class Counter:
         _lib.check(_lib.lib().brx_counter_device_counts(self._h, C.byref(p), C.byref(n)))
         return p.value, n.value
 
+    def reset(self, stream: Optional[int] = None) -> None:
+        _lib.check(_lib.lib().brx_counter_reset(self._h, stream))
+
+    def finish_into(self, abundance: int, dst: "Pcon", stream: Optional[int] = None) -> None:
+        _lib.check(_lib.lib().brx_set_count_finish_into(self._h, abundance, stream, dst._h))
+
     def finish(self, abundance: int, stream: Optional[int] = None) -> Pcon:
         """Solid::from_count(k, counts, abundance): solid iff count > abundance."""
         h = C.c_void_p()

@@ -113,6 +113,10 @@ int brx_set_count_add_batch_device(brx_counter_t *c, const uint8_t *d_bases, con
 /* solid iff count > abundance (strict; pinned by tests/data/raw.k11.a2.solid).  The counter
  * stays valid (finish may be called again with another abundance) until freed.             */
 int brx_set_count_finish(brx_counter_t *c, uint8_t abundance, void *stream, brx_set_t **out);
+/* same, into an existing set of the same k/device (no allocation; asynchronous on `stream`)  */
+int brx_set_count_finish_into(brx_counter_t *c, uint8_t abundance, void *stream, brx_set_t *dst);
+/* forget everything counted so far (Counter::new without re-allocating; async on `stream`)   */
+int brx_counter_reset(brx_counter_t *c, void *stream);
 /* dense strategy only: device view of the u8 table, for the RCCL reduction of SURVEY 8(e)   */
 int brx_counter_device_counts(brx_counter_t *c, void **d_counts, uint64_t *n_bytes);
 /* clamp every count to min(count, cap) in place (the exact-sum trick before an u8 all-reduce) */
