@@ -40,7 +40,7 @@ int upload_batch(const uint8_t *bases, const uint64_t *offsets, uint32_t n_reads
 namespace {
 
 // control block layout (u64 words)
-enum { CTL_WORK = 0, CTL_OVERFLOW = 1, CTL_ROUNDS = 2, CTL_PROBES = 3, CTL_TRIGGERS = 4, CTL_FIXES = 5, CTL_TOTAL = 6, CTL_N = 8 };
+enum { CTL_WORK = 0, CTL_OVERFLOW = 1, CTL_ROUNDS = 2, CTL_PROBES = 3, CTL_TRIGGERS = 4, CTL_FIXES = 5, CTL_TOTAL = 6, CTL_PATHOVF = 7, CTL_N = 8 };
 
 struct PassParams {
     const uint32_t *bits;
@@ -58,6 +58,9 @@ struct PassParams {
     uint32_t *out_lens;
     uint32_t slack;          // slot(r) = o + (o>>2)*slack + 64*r
     unsigned long long *ctrl;
+    // graph walks (Graph, GapSize): per-group list of visited k-mers, maxpath entries each
+    uint64_t *path_k;
+    uint32_t maxpath;
 };
 
 __device__ __forceinline__ uint64_t slot_of(uint64_t o, uint64_t r, uint32_t slack)
@@ -71,11 +74,99 @@ __device__ __forceinline__ bool probe(const uint32_t *__restrict__ bits, uint64_
     return (bits[h >> 5] >> (h & 31u)) & 1u;
 }
 
-enum { ST_INIT = 0, ST_SCAN = 1, ST_ALTS = 2, ST_SCEN = 3, ST_MORE = 4 };
+enum { ST_INIT = 0, ST_SCAN, ST_ERRLEN, ST_ALTS, ST_SCEN, ST_MORE, ST_WALK, ST_T1, ST_TSCORE, ST_TMORE };
+enum { MODE_ONE = 0, MODE_GRAPH = 1, MODE_INSSUB = 2, MODE_TWO = 3 };
 
-template <int G>
-__global__ __launch_bounds__(256) void correct_one_kernel(PassParams p)
+// ---- ScenarioTwo (src/correct/exist/two.rs:34-328), ids in declaration order ---------------------
+enum { T_II, T_IS, T_SS, T_SD, T_DD, T_ICI, T_ICS, T_ICD, T_SCI, T_SCS, T_SCD, T_DCI, T_DCD, T_N };
+
+// Everything ScenarioTwo::apply needs once the 16 stage-1 probes are back:
+//   K      the corrected k-mer (exist/mod.rs:129)
+//   s[j]   2-bit code of seq[j], j < 4 (seq = read from the trigger position on)
+//   m1     16 solidity bits: family f = bit>>2 in {B: add(K,a), C: add(add(K,s2),a),
+//          D: add(add(K,s1),a), E: add(add(K,s0),a)}, a = bit&3
+struct TwoCtx {
+    uint64_t K;
+    uint32_t s; // s0 | s1<<2 | s2<<4 | s3<<6
+    uint32_t m1;
+};
+
+__device__ __forceinline__ uint32_t two_s(const TwoCtx &t, int j) { return (t.s >> (2 * j)) & 3u; }
+__device__ __forceinline__ uint32_t two_fam(const TwoCtx &t, int f) { return (t.m1 >> (4 * f)) & 0xfu; }
+
+// ScenarioTwo::apply -> (kmer, offset); only meaningful for scenarios whose validity bit is set
+__device__ __forceinline__ uint64_t two_apply(const TwoCtx &t, int sc, uint64_t mask, uint32_t &off)
 {
+    const uint64_t K = t.K;
+    const uint64_t altB = (uint64_t)(__ffs(two_fam(t, 0)) - 1) & 3u, altC = (uint64_t)(__ffs(two_fam(t, 1)) - 1) & 3u;
+    const uint64_t altD = (uint64_t)(__ffs(two_fam(t, 2)) - 1) & 3u, altE = (uint64_t)(__ffs(two_fam(t, 3)) - 1) & 3u;
+    switch (sc) {
+    case T_II: off = 3; return K;                                                    // two.rs:96
+    case T_IS: off = 2; return K;                                                    // two.rs:97
+    case T_SS: off = 2; return add_nuc(K, altB, mask);                               // two.rs:98-114
+    case T_SD: off = 1; return add_nuc(K, altB, mask);                               // two.rs:115-126
+    case T_DD: off = 0; return add_nuc(K, altB, mask);                               // two.rs:127-134
+    case T_ICI: off = 4; return add_nuc(K, two_s(t, 3), mask);                       // two.rs:135-148
+    case T_ICS: off = 3; return add_nuc(K, altB, mask);                              // two.rs:149-166
+    case T_ICD: off = 3; return add_nuc(add_nuc(K, two_s(t, 2), mask), altC, mask);  // two.rs:167-181
+    case T_SCI:
+    case T_DCI: off = 4; return add_nuc(add_nuc(K, two_s(t, 1), mask), two_s(t, 3), mask); // two.rs:182-191,231-240
+    case T_SCS: off = 3; return add_nuc(add_nuc(K, two_s(t, 1), mask), altD, mask);  // two.rs:192-215
+    case T_SCD: off = 2; return add_nuc(add_nuc(K, two_s(t, 1), mask), altD, mask);  // two.rs:216-230
+    default: off = 1; return add_nuc(add_nuc(K, two_s(t, 0), mask), altE, mask);     // DCD two.rs:241-254
+    }
+}
+
+// which scenarios return Some(..) from apply AND pass get_score's `get(kmer)` test (exist/mod.rs:22-25)
+__device__ __forceinline__ uint32_t two_valid(const TwoCtx &t, uint32_t rem)
+{
+    const uint32_t B = two_fam(t, 0), C = two_fam(t, 1), D = two_fam(t, 2), E = two_fam(t, 3);
+    const bool nB = __popc(B) == 1, nC = __popc(C) == 1, nD = __popc(D) == 1, nE = __popc(E) == 1;
+    const bool b_s1 = (B >> two_s(t, 1)) & 1u, b_s3 = (B >> two_s(t, 3)) & 1u;
+    const bool d_s2 = (D >> two_s(t, 2)) & 1u, d_s3 = (D >> two_s(t, 3)) & 1u;
+    uint32_t v = (1u << T_II) | (1u << T_IS);
+    if (rem >= 2 && !b_s1 && nB) v |= 1u << T_SS;
+    if (nB) v |= (1u << T_SD) | (1u << T_DD);
+    if (rem >= 4 && b_s3) v |= 1u << T_ICI;
+    if (rem >= 4 && !b_s1 && nB) v |= 1u << T_ICS;
+    if (rem >= 4 && nC) v |= 1u << T_ICD;
+    if (rem >= 4 && d_s3) v |= (1u << T_SCI) | (1u << T_DCI);
+    if (rem >= 3 && b_s1 && !d_s2 && nD) v |= 1u << T_SCS;
+    if (rem >= 2 && nD) v |= 1u << T_SCD;
+    if (rem >= 2 && nE) v |= 1u << T_DCD;
+    return v;
+}
+
+// ScenarioTwo::correct -> (bases packed 2 bits each, first base in the high bits; count; offset) two.rs:258-325
+__device__ __forceinline__ uint32_t two_correct(const TwoCtx &t, int sc, uint64_t mask, uint32_t &nc, uint32_t &offc)
+{
+    uint32_t off;
+    const uint64_t ck = two_apply(t, sc, mask, off);
+    switch (sc) {
+    case T_II:
+    case T_IS: nc = 1; offc = 2; return (uint32_t)(t.K & 3u);
+    case T_SS:
+    case T_SD:
+    case T_DD: nc = 2; offc = off; return (uint32_t)(ck & 0xfu);
+    case T_ICI: nc = 1; offc = 3; return (uint32_t)(t.K & 3u);
+    case T_ICD: nc = 2; offc = off - 1; return (uint32_t)(ck & 0xfu);
+    case T_ICS: nc = 2; offc = off + 1; return (uint32_t)(ck & 0xfu);
+    case T_SCI:
+    case T_SCS:
+    case T_SCD:
+    case T_DCD: nc = 3; offc = off; return (uint32_t)(ck & 0x3fu);
+    default: nc = 0; offc = 1; return 0; // DCI, two.rs:323
+    }
+}
+
+template <int G, int M>
+__global__ __launch_bounds__(256) void correct_kernel(PassParams p)
+{
+    constexpr bool HAS_ERRLEN = (M == BRX_GRAPH || M == BRX_GAP_SIZE);
+    constexpr bool HAS_ONE = (M == BRX_ONE || M == BRX_GAP_SIZE);
+    constexpr bool HAS_WALK = HAS_ERRLEN;
+    constexpr bool HAS_TWO = (M == BRX_TWO);
+
     const int lane = threadIdx.x & 63;
     const int gl = lane & (G - 1);
     const int gshift = lane & ~(G - 1);
@@ -83,6 +174,8 @@ __global__ __launch_bounds__(256) void correct_one_kernel(PassParams p)
     const int k = p.k;
     const uint32_t c = (uint32_t)p.c;
     const uint64_t mask = kmask(k);
+    const uint32_t gid = blockIdx.x * (256 / G) + threadIdx.x / G; // global group index (path scratch slot)
+    unsigned long long *path = HAS_WALK ? (unsigned long long *)p.path_k + (uint64_t)gid * p.maxpath : nullptr;
 
     // group-uniform state (replicated in every lane of the group)
     uint32_t r = 0, n = 0, cap = 0, i = 0, olen = 0;
@@ -90,9 +183,14 @@ __global__ __launch_bounds__(256) void correct_one_kernel(PassParams p)
     uint8_t *out = nullptr;
     uint64_t kmer = 0, corr = 0;
     bool prev = false, have = false;
-    int st = ST_INIT;
+    int st = ST_INIT, mode = HAS_TWO ? MODE_TWO : (M == BRX_GRAPH ? MODE_GRAPH : MODE_ONE);
     uint32_t sub = 0, failmask = 0, passmask = 0;
     uint8_t ch_t = 0;
+    // error_len / walk state
+    uint32_t elen = 0, ej = 0, npath = 0, gap = 0;
+    uint64_t fc = 0, ek = 0, wk = 0;
+    TwoCtx tw = {0, 0, 0};
+    uint32_t tvalid = 0;
     // statistics
     uint32_t n_rounds = 0, n_probes = 0, n_trig = 0, n_fix = 0;
 
@@ -135,6 +233,25 @@ __global__ __launch_bounds__(256) void correct_one_kernel(PassParams p)
         }
         fetch();
     };
+    auto path_overflow = [&]() {
+        if (gl == 0) {
+            p.out_lens[r] = 0xffffffffu;
+            atomicAdd(p.ctrl + CTL_PATHOVF, 1ull);
+        }
+        fetch();
+    };
+    // k-mer of this lane after appending the 2-bit codes of lanes 0..gl of the group to `carry`
+    auto lane_kmer = [&](uint64_t carry, uint64_t code) -> uint64_t {
+        uint64_t val = code;
+#pragma unroll
+        for (int d = 1; d < G && d < 32; d <<= 1) {
+            const uint64_t other = __shfl_up(val, d, G);
+            if (gl >= d)
+                val |= other << (2 * d);
+        }
+        const int nb = gl + 1;
+        return (nb >= k) ? (val & mask) : (((carry << (2 * nb)) | val) & mask);
+    };
 
     fetch();
 
@@ -142,7 +259,7 @@ __global__ __launch_bounds__(256) void correct_one_kernel(PassParams p)
         bool do_probe = false;
         uint64_t pk = 0;
         uint8_t ch = 0;
-        uint32_t sc_s = 0;      // scenario index of this lane in SCEN
+        uint32_t sc_s = 0; // scenario index of this lane in SCEN / TSCORE
         bool sc_active = false;
 
         // ---------------- phase 1: choose this round's probe --------------------------------
@@ -150,10 +267,7 @@ __global__ __launch_bounds__(256) void correct_one_kernel(PassParams p)
             n_rounds += (gl == 0);
             if (st == ST_INIT) {
                 if (n < (uint32_t)k) {
-                    // mod.rs:56-58: shorter than k, returned verbatim
-                    if (n > cap) {
-                        // cannot happen (cap >= n + 64) but keep the invariant explicit
-                    }
+                    // mod.rs:56-58: shorter than k, returned verbatim (cap >= n + 64 always)
                     for (uint32_t j = gl; j < n; j += G)
                         out[j] = ld(j);
                     olen = n;
@@ -173,21 +287,20 @@ __global__ __launch_bounds__(256) void correct_one_kernel(PassParams p)
                 const uint32_t pos = i + (uint32_t)gl;
                 const bool valid = pos < n;
                 ch = valid ? ld(pos) : (uint8_t)0;
-                // inclusive concat-scan of the 2-bit codes over the lanes of the group
-                uint64_t val = nuc2bit(ch);
-#pragma unroll
-                for (int d = 1; d < G && d < 32; d <<= 1) {
-                    const uint64_t other = __shfl_up(val, d, G);
-                    if (gl >= d)
-                        val |= other << (2 * d);
-                }
-                const int nb = gl + 1;
-                pk = (nb >= k) ? (val & mask) : (((kmer << (2 * nb)) | val) & mask);
+                pk = lane_kmer(kmer, nuc2bit(ch));
+                do_probe = valid;
+            } else if (HAS_ERRLEN && st == ST_ERRLEN) {
+                // error_len, mod.rs:130-152: probe seq[i+1..] until the first solid k-mer
+                const uint32_t rem = n - i;
+                const uint32_t j = ej + 1u + (uint32_t)gl;
+                const bool valid = j < rem;
+                const uint8_t c2 = valid ? ld(i + j) : (uint8_t)0;
+                pk = lane_kmer(ek, nuc2bit(c2));
                 do_probe = valid;
             } else if (st == ST_ALTS) {
                 do_probe = gl < 4;
                 pk = add_nuc(kmer >> 2, (uint64_t)gl, mask);
-            } else if (st == ST_SCEN) {
+            } else if (HAS_ONE && st == ST_SCEN) {
                 const uint32_t e = sub * G + (uint32_t)gl;
                 sc_active = e < 3u * c;
                 sc_s = sc_active ? e / c : 0u;
@@ -200,7 +313,7 @@ __global__ __launch_bounds__(256) void correct_one_kernel(PassParams p)
                         pk = add_nuc(pk, nuc2bit(ld(i + off + q)), mask);
                     do_probe = true;
                 }
-            } else { // ST_MORE
+            } else if (HAS_ONE && st == ST_MORE) {
                 if (gl < 3 && ((passmask >> gl) & 1u)) {
                     const uint32_t off = 2u - (uint32_t)gl;
                     const uint32_t rem = n - i;
@@ -208,6 +321,49 @@ __global__ __launch_bounds__(256) void correct_one_kernel(PassParams p)
                         pk = corr;
                         for (uint32_t q = 0; q <= c; q++)
                             pk = add_nuc(pk, nuc2bit(ld(i + off + q)), mask);
+                        do_probe = true;
+                    }
+                }
+            } else if (HAS_WALK && st == ST_WALK) {
+                do_probe = gl < 4; // next_nucs(kmer), mod.rs:118-128
+                pk = add_nuc(wk, (uint64_t)gl, mask);
+            } else if (HAS_TWO && st == ST_T1) {
+                // the 16 distinct probes behind every ScenarioTwo::apply (see TwoCtx)
+                const uint32_t rem = n - i;
+                const int fam = gl >> 2;
+                if (gl < 16) {
+                    uint64_t basek = corr;
+                    bool ok = true;
+                    if (fam == 1) { ok = rem >= 3; basek = add_nuc(corr, two_s(tw, 2), mask); }
+                    else if (fam == 2) { ok = rem >= 2; basek = add_nuc(corr, two_s(tw, 1), mask); }
+                    else if (fam == 3) { basek = add_nuc(corr, two_s(tw, 0), mask); }
+                    pk = add_nuc(basek, (uint64_t)(gl & 3), mask);
+                    do_probe = ok;
+                }
+            } else if (HAS_TWO && st == ST_TSCORE) {
+                const uint32_t e = sub * G + (uint32_t)gl;
+                sc_active = e < (uint32_t)T_N * c;
+                sc_s = sc_active ? e / c : 0u;
+                const uint32_t j = sc_active ? e % c : 0u;
+                sc_active = sc_active && ((tvalid >> sc_s) & 1u) && !((failmask >> sc_s) & 1u);
+                if (sc_active) {
+                    uint32_t off;
+                    pk = two_apply(tw, (int)sc_s, mask, off);
+                    for (uint32_t q = 0; q <= j; q++) // get_score look-ahead, exist/mod.rs:33-41
+                        pk = add_nuc(pk, nuc2bit(ld(i + off + q)), mask);
+                    do_probe = true;
+                }
+            } else if (HAS_TWO && st == ST_TMORE) {
+                if (gl < T_N && ((passmask >> gl) & 1u)) {
+                    uint32_t nc, offc;
+                    const uint32_t cb = two_correct(tw, gl, mask, nc, offc);
+                    const uint32_t rem = n - i;
+                    if (rem > c + offc + 1u) { // exist/mod.rs:54
+                        pk = corr >> 2;
+                        for (uint32_t q = 0; q < nc; q++)
+                            pk = add_nuc(pk, (uint64_t)((cb >> (2 * (nc - 1 - q))) & 3u), mask);
+                        for (uint32_t q = 0; q <= c; q++)
+                            pk = add_nuc(pk, nuc2bit(ld(i + offc + q)), mask);
                         do_probe = true;
                     }
                 }
@@ -226,7 +382,10 @@ __global__ __launch_bounds__(256) void correct_one_kernel(PassParams p)
         // ---------------- phase 3: group-uniform transitions ----------------------------------
         if (have) {
             bool fail = false;   // correct_error returned None
-            int apply_s = -1;    // scenario to apply
+            int apply_s = -1;    // One scenario to apply
+            int apply_t = -1;    // Two scenario to apply
+            bool apply_path = false;
+            uint32_t path_offset = 0;
             if (st == ST_INIT) {
                 if (n < (uint32_t)k) {
                     finish();
@@ -254,8 +413,14 @@ __global__ __launch_bounds__(256) void correct_one_kernel(PassParams p)
                     if (trig) {
                         kmer = __shfl(pk, gshift + (int)nacc);
                         ch_t = (uint8_t)__shfl((int)ch, gshift + (int)nacc);
-                        st = ST_ALTS;
                         n_trig += (gl == 0);
+                        if (HAS_ERRLEN) {
+                            st = ST_ERRLEN;
+                            ej = 0;
+                            ek = kmer;
+                        } else {
+                            st = ST_ALTS;
+                        }
                     } else {
                         kmer = __shfl(pk, gshift + (int)nacc - 1);
                         prev = (gmask >> (nacc - 1)) & 1ull; // mod.rs:99
@@ -263,36 +428,92 @@ __global__ __launch_bounds__(256) void correct_one_kernel(PassParams p)
                             finish();
                     }
                 }
+            } else if (HAS_ERRLEN && st == ST_ERRLEN) {
+                const uint32_t rem = n - i;
+                const uint32_t first = ej + 1u;
+                const uint32_t left = rem > first ? rem - first : 0u;
+                const uint32_t nvalid = left < (uint32_t)G ? left : (uint32_t)G;
+                const uint64_t vmask = (nvalid >= 64) ? ~0ull : ((1ull << nvalid) - 1ull);
+                const uint64_t smask = gmask & vmask;
+                bool done = false, hit_end = false;
+                if (smask) {
+                    const int t = __builtin_ctzll(smask);
+                    elen = first + (uint32_t)t;
+                    fc = __shfl(pk, gshift + t);
+                    done = true;
+                } else if (nvalid < (uint32_t)G) {
+                    elen = rem; // ran off the read: the last k-mer built is not solid
+                    const uint64_t last = __shfl(pk, gshift + (nvalid ? (int)nvalid - 1 : 0));
+                    fc = nvalid ? last : ek;
+                    done = true;
+                    hit_end = true;
+                } else {
+                    ek = __shfl(pk, gshift + G - 1);
+                    ej += G;
+                }
+                if (done) {
+                    if (M == BRX_GRAPH) {
+                        mode = MODE_GRAPH;
+                    } else { // gap_size.rs:97-108
+                        if (elen < (uint32_t)k)
+                            mode = MODE_GRAPH;
+                        else if (elen == (uint32_t)k)
+                            mode = MODE_ONE;
+                        else {
+                            mode = MODE_INSSUB;
+                            gap = elen - (uint32_t)k;
+                        }
+                    }
+                    // Graph with a non-solid target: every walk k-mer is solid, so `kmer ==
+                    // first_correct_kmer` (graph.rs:79) can never hold and the walk can only end in
+                    // None (branch, dead end or revisit) -- same outcome, no walk.
+                    if (mode == MODE_GRAPH && hit_end)
+                        fail = true;
+                    else
+                        st = ST_ALTS;
+                }
             } else if (st == ST_ALTS) {
                 const uint32_t am = (uint32_t)(gmask & 0xfull);
                 if (__popc(am) != 1) {
-                    fail = true; // exist/mod.rs:123-126
+                    fail = true; // exist/mod.rs:123-126, graph.rs:51-55, gap_size.rs:47-50
                 } else {
                     corr = add_nuc(kmer >> 2, (uint64_t)(__ffs(am) - 1), mask);
                     const uint32_t rem = n - i;
-                    failmask = 0;
-                    for (uint32_t s = 0; s < 3; s++)
-                        if ((2u - s) + c > rem) // exist/mod.rs:27-29
-                            failmask |= 1u << s;
-                    if (failmask == 7u || c == 0u) {
-                        // c == 0: every scenario trivially scores 0 == c; handled below
-                        if (c == 0u) {
+                    if (HAS_ONE && mode == MODE_ONE) {
+                        failmask = 0;
+                        for (uint32_t s = 0; s < 3; s++)
+                            if ((2u - s) + c > rem) // exist/mod.rs:27-29
+                                failmask |= 1u << s;
+                        if (failmask == 7u) {
+                            fail = true;
+                        } else if (c == 0u) {
                             passmask = 7u & ~failmask;
-                            if (passmask == 0)
-                                fail = true;
-                            else if (__popc(passmask) == 1)
+                            if (__popc(passmask) == 1)
                                 apply_s = __ffs(passmask) - 1;
                             else
                                 st = ST_MORE;
                         } else {
-                            fail = true;
+                            sub = 0;
+                            st = ST_SCEN;
                         }
-                    } else {
-                        sub = 0;
-                        st = ST_SCEN;
+                    } else if (HAS_WALK && (mode == MODE_GRAPH || mode == MODE_INSSUB)) {
+                        // graph.rs:57-59 / gap_size.rs:52-55: path = [alt], viewed = {corr}
+                        if (gl == 0)
+                            __hip_atomic_store(path, (unsigned long long)corr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        npath = 1;
+                        wk = corr;
+                        st = ST_WALK;
+                    } else if (HAS_TWO) {
+                        uint32_t s4 = 0;
+                        for (uint32_t j = 0; j < 4 && j < rem; j++)
+                            s4 |= (uint32_t)nuc2bit(ld(i + j)) << (2 * j);
+                        tw.K = corr;
+                        tw.s = s4;
+                        tw.m1 = 0;
+                        st = ST_T1;
                     }
                 }
-            } else if (st == ST_SCEN) {
+            } else if (HAS_ONE && st == ST_SCEN) {
                 const bool bad = sc_active && !sol;
 #pragma unroll
                 for (uint32_t s = 0; s < 3; s++) {
@@ -310,10 +531,94 @@ __global__ __launch_bounds__(256) void correct_one_kernel(PassParams p)
                     else
                         st = ST_MORE;
                 }
-            } else { // ST_MORE
+            } else if (HAS_ONE && st == ST_MORE) {
                 const uint32_t keep = (uint32_t)(gmask & 7ull) & passmask;
                 if (__popc(keep) == 1)
                     apply_s = __ffs(keep) - 1; // exist/mod.rs:143-144
+                else
+                    fail = true;
+            } else if (HAS_WALK && st == ST_WALK) {
+                const uint32_t am = (uint32_t)(gmask & 0xfull);
+                if (__popc(am) != 1) {
+                    fail = true; // graph.rs:64-67, gap_size.rs:60-68
+                } else {
+                    const uint64_t nk = add_nuc(wk, (uint64_t)(__ffs(am) - 1), mask);
+                    bool hit = false; // viewed_kmer.contains(&kmer): graph.rs:71, gap_size.rs:75
+                    for (uint32_t j = gl; j < npath; j += G)
+                        hit |= __hip_atomic_load(path + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nk;
+                    const uint64_t anyhit = (__ballot(hit) >> gshift) & GM;
+                    if (anyhit) {
+                        fail = true;
+                    } else if (npath >= p.maxpath) {
+                        path_overflow();
+                    } else {
+                        if (gl == 0)
+                            __hip_atomic_store(path + npath, (unsigned long long)nk, __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_AGENT);
+                        npath++;
+                        wk = nk;
+                        if (mode == MODE_GRAPH) {
+                            if (nk == fc) { // graph.rs:79-81
+                                apply_path = true;
+                                path_offset = elen + 1u; // graph.rs:84
+                            }
+                        } else if (--gap == 0u) {
+                            apply_path = true;
+                            path_offset = npath; // gap_size.rs:87-88
+                        }
+                    }
+                }
+            } else if (HAS_TWO && st == ST_T1) {
+                const uint32_t rem = n - i;
+                tw.m1 = (uint32_t)(gmask & 0xffffull);
+                tvalid = two_valid(tw, rem);
+                for (int sc = 0; sc < T_N; sc++) { // exist/mod.rs:27-29
+                    uint32_t off;
+                    (void)two_apply(tw, sc, mask, off);
+                    if (off + c > rem)
+                        tvalid &= ~(1u << sc);
+                }
+                if (tvalid == 0u) {
+                    fail = true;
+                } else if (c == 0u) {
+                    passmask = tvalid;
+                    if (__popc(passmask) == 1)
+                        apply_t = __ffs(passmask) - 1;
+                    else
+                        st = ST_TMORE;
+                } else {
+                    failmask = 0;
+                    sub = 0;
+                    st = ST_TSCORE;
+                }
+            } else if (HAS_TWO && st == ST_TSCORE) {
+                const bool bad = sc_active && !sol;
+                const uint64_t badmask = (__ballot(bad) >> gshift) & GM;
+                const uint32_t e0 = sub * G;
+                const uint32_t sc_first = e0 / c;
+                const uint32_t sc_last = (e0 + G - 1u) / c;
+                for (uint32_t sc = sc_first; sc <= sc_last && sc < (uint32_t)T_N; sc++) {
+                    const uint32_t lo = sc * c > e0 ? sc * c - e0 : 0u;
+                    const uint32_t hi_abs = (sc + 1u) * c;
+                    const uint32_t hi = hi_abs - e0 < (uint32_t)G ? hi_abs - e0 : (uint32_t)G;
+                    const uint64_t seg = ((hi - lo) >= 64u ? ~0ull : ((1ull << (hi - lo)) - 1ull)) << lo;
+                    if (badmask & seg)
+                        failmask |= 1u << sc;
+                }
+                sub++;
+                passmask = tvalid & ~failmask;
+                if (passmask == 0u) {
+                    fail = true;
+                } else if (sub * G >= (uint32_t)T_N * c) {
+                    if (__popc(passmask) == 1)
+                        apply_t = __ffs(passmask) - 1;
+                    else
+                        st = ST_TMORE;
+                }
+            } else if (HAS_TWO && st == ST_TMORE) {
+                const uint32_t keep = (uint32_t)(gmask & ((1ull << T_N) - 1ull)) & passmask;
+                if (__popc(keep) == 1)
+                    apply_t = __ffs(keep) - 1;
                 else
                     fail = true;
             }
@@ -344,6 +649,47 @@ __global__ __launch_bounds__(256) void correct_one_kernel(PassParams p)
                     kmer = corr;
                     prev = true;
                     i += 2u - (uint32_t)apply_s;
+                    n_fix += (gl == 0);
+                    if (i >= n)
+                        finish();
+                    else
+                        st = ST_SCAN;
+                }
+            } else if (HAS_TWO && apply_t >= 0) {
+                // mod.rs:75-89 with two.rs:258-325
+                uint32_t nc, offc;
+                const uint32_t cb = two_correct(tw, apply_t, mask, nc, offc);
+                if (olen + nc + 1u > cap) {
+                    overflow();
+                } else {
+                    uint64_t km = kmer >> 2;
+                    for (uint32_t q = 0; q < nc; q++) {
+                        const uint64_t b = (cb >> (2 * (nc - 1 - q))) & 3u;
+                        km = add_nuc(km, b, mask);
+                        if (gl == 0)
+                            out[olen + q] = bit2nuc(b);
+                    }
+                    olen += nc;
+                    kmer = km;
+                    prev = true;
+                    i += offc;
+                    n_fix += (gl == 0);
+                    if (i >= n)
+                        finish();
+                    else
+                        st = ST_SCAN;
+                }
+            } else if (HAS_WALK && apply_path) {
+                // mod.rs:75-89: the whole walked path replaces `path_offset` read bases
+                if (olen + npath + 1u > cap) {
+                    overflow();
+                } else {
+                    for (uint32_t j = gl; j < npath; j += G)
+                        out[olen + j] = bit2nuc(__hip_atomic_load(path + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 3ull);
+                    olen += npath;
+                    kmer = wk;
+                    prev = true;
+                    i += path_offset;
                     n_fix += (gl == 0);
                     if (i >= n)
                         finish();
@@ -424,29 +770,48 @@ int group_width()
     return (g == 16 || g == 32 || g == 64) ? g : 16;
 }
 
-int launch_pass(const brx_chain *ch, const PassParams &p, int method, hipStream_t s)
+constexpr uint32_t MAX_BLOCKS = 256u * 8u;
+
+uint32_t pass_blocks(uint32_t n_reads, int G)
 {
-    if (method != BRX_ONE) {
-        set_error("correction method %d not implemented on the GPU path yet", method);
+    const uint32_t groups_per_block = 256u / (uint32_t)G;
+    // persistent-ish grid: enough groups to fill the chip, reads pulled from a work counter
+    uint64_t want = ((uint64_t)n_reads + groups_per_block - 1) / groups_per_block;
+    if (want > MAX_BLOCKS)
+        want = MAX_BLOCKS;
+    if (want < 1)
+        want = 1;
+    return (uint32_t)want;
+}
+
+template <int M>
+void launch_method(const PassParams &p, int G, uint32_t blocks, hipStream_t s)
+{
+    if (G == 16)
+        correct_kernel<16, M><<<blocks, 256, 0, s>>>(p);
+    else if (G == 32)
+        correct_kernel<32, M><<<blocks, 256, 0, s>>>(p);
+    else
+        correct_kernel<64, M><<<blocks, 256, 0, s>>>(p);
+}
+
+int launch_pass(const PassParams &p, int method, int G, hipStream_t s)
+{
+    const uint32_t blocks = pass_blocks(p.n_reads, G);
+    static const char *names[5] = {"correct_pass", "correct_pass_two", "correct_pass_graph", "correct_pass_greedy",
+                                   "correct_pass_gap_size"};
+    if (method == BRX_GREEDY) {
+        set_error("correction method greedy not implemented on the GPU path yet");
         return BRX_ERR_UNSUPPORTED;
     }
-    (void)ch;
-    const int G = group_width();
-    const uint32_t groups_per_block = 256 / G;
-    // persistent-ish grid: enough groups to fill the chip, reads pulled from a work counter
-    uint64_t want_blocks = ((uint64_t)p.n_reads + groups_per_block - 1) / groups_per_block;
-    const uint64_t max_blocks = 256ull * 8ull;
-    if (want_blocks > max_blocks)
-        want_blocks = max_blocks;
-    if (want_blocks < 1)
-        want_blocks = 1;
-    KernelTimer t("correct_pass", s);
-    if (G == 16)
-        correct_one_kernel<16><<<(int)want_blocks, 256, 0, s>>>(p);
-    else if (G == 32)
-        correct_one_kernel<32><<<(int)want_blocks, 256, 0, s>>>(p);
-    else
-        correct_one_kernel<64><<<(int)want_blocks, 256, 0, s>>>(p);
+    KernelTimer t(names[method], s);
+    switch (method) {
+    case BRX_ONE: launch_method<BRX_ONE>(p, G, blocks, s); break;
+    case BRX_TWO: launch_method<BRX_TWO>(p, G, blocks, s); break;
+    case BRX_GRAPH: launch_method<BRX_GRAPH>(p, G, blocks, s); break;
+    case BRX_GAP_SIZE: launch_method<BRX_GAP_SIZE>(p, G, blocks, s); break;
+    default: break;
+    }
     BRX_HIP(hipGetLastError());
     return BRX_OK;
 }
@@ -482,6 +847,8 @@ int brx_chain_new(const brx_set_t *set, const brx_method_t *methods, uint32_t n_
     ch->scan_tmp_cap = 0;
     ch->d_ctrl = nullptr;
     ch->h_ctrl = nullptr;
+    ch->d_path = nullptr;
+    ch->path_bytes = 0;
     ch->d_in = nullptr;
     ch->d_in_cap = 0;
     ch->d_off = nullptr;
@@ -551,11 +918,20 @@ int brx_chain_correct_batch_device(brx_chain_t *ch, const uint8_t *d_bases, cons
     const int n_dirs = ch->two_side ? 1 : 2;
     const int n_methods = (int)ch->methods.size();
     uint64_t stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const int G = group_width();
+    bool needs_path = false;
+    for (int m = 0; m < n_methods; m++)
+        needs_path |= (ch->methods[m].method == BRX_GRAPH || ch->methods[m].method == BRX_GAP_SIZE);
+    uint32_t maxpath = 512;
 
-    for (uint32_t slack = 1, attempt = 0;; slack *= 4, attempt++) {
-        if (attempt > 6) {
-            set_error("correction output does not fit 4096x the input size; giving up");
+    for (uint32_t slack = 1, attempt = 0;; attempt++) {
+        if (attempt > 12) {
+            set_error("correction output / graph walks do not fit the workspace after 12 enlargements; giving up");
             return BRX_ERR_OVERFLOW;
+        }
+        if (needs_path) {
+            const uint64_t n_groups = (uint64_t)pass_blocks(n_reads, G) * (256u / (uint32_t)G);
+            BRX_TRY(ensure((void **)&ch->d_path, &ch->path_bytes, n_groups * maxpath * 8ull));
         }
         const uint64_t stage_need = total_bases + (total_bases >> 2) * slack + 64ull * ((uint64_t)n_reads + 1) + 64;
         if (stage_need > ch->stage_bytes || !ch->d_stage[0]) {
@@ -592,8 +968,10 @@ int brx_chain_correct_batch_device(brx_chain_t *ch, const uint8_t *d_bases, cons
                 p.out_lens = ch->d_lens[pp];
                 p.slack = slack;
                 p.ctrl = (unsigned long long *)ch->d_ctrl;
+                p.path_k = ch->d_path;
+                p.maxpath = maxpath;
                 BRX_HIP(hipMemsetAsync(ch->d_ctrl + CTL_WORK, 0, 8, s));
-                BRX_TRY(launch_pass(ch, p, ch->methods[m].method, s));
+                BRX_TRY(launch_pass(p, ch->methods[m].method, G, s));
                 cur = ch->d_stage[pp];
                 cur_lens = ch->d_lens[pp];
                 cur_staged = 1;
@@ -609,8 +987,15 @@ int brx_chain_correct_batch_device(brx_chain_t *ch, const uint8_t *d_bases, cons
         BRX_HIP(hipMemcpyAsync(ch->h_ctrl, ch->d_ctrl, CTL_N * 8, hipMemcpyDeviceToHost, s));
         BRX_HIP(hipStreamSynchronize(s));
         stats[4] = attempt;
-        if (ch->h_ctrl[CTL_OVERFLOW] != 0)
-            continue; // some read outgrew its slot: redo the batch with 4x the slack
+        if (ch->h_ctrl[CTL_OVERFLOW] != 0 || ch->h_ctrl[CTL_PATHOVF] != 0) {
+            // some read outgrew its output slot / a graph walk outgrew its visited list: redo the
+            // batch on the GPU with a larger workspace (never on the CPU)
+            if (ch->h_ctrl[CTL_OVERFLOW] != 0)
+                slack *= 4;
+            if (ch->h_ctrl[CTL_PATHOVF] != 0)
+                maxpath *= 8;
+            continue;
+        }
         stats[0] = ch->h_ctrl[CTL_ROUNDS];
         stats[1] = ch->h_ctrl[CTL_PROBES];
         stats[2] = ch->h_ctrl[CTL_TRIGGERS];
@@ -722,6 +1107,8 @@ void brx_chain_free(brx_chain_t *ch)
             (void)hipFree(ch->d_scan_tmp);
         if (ch->d_ctrl)
             (void)hipFree(ch->d_ctrl);
+        if (ch->d_path)
+            (void)hipFree(ch->d_path);
         if (ch->h_ctrl)
             (void)hipHostFree(ch->h_ctrl);
         if (ch->d_in)

@@ -89,6 +89,8 @@ struct brx_chain {
     uint64_t lens_cap;
     uint64_t *d_scan_tmp;
     uint64_t scan_tmp_cap;
+    uint64_t *d_path;   // graph-walk visited lists (Graph / GapSize)
+    uint64_t path_bytes;
     uint64_t *d_ctrl;   // device control block (work counter, overflow, stats)
     uint64_t *h_ctrl;   // pinned mirror
     // host-entry staging

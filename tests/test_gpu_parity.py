@@ -15,7 +15,7 @@ from oracle import oracle as O
 
 pytestmark = pytest.mark.gpu
 
-IMPLEMENTED = {"one"}  # methods with a GPU kernel so far; the others must fail loudly
+IMPLEMENTED = {"one", "two", "graph", "gap_size"}  # methods with a GPU kernel; the others must fail loudly
 
 
 def _oracle_set(v):
@@ -161,7 +161,7 @@ def test_unit_vectors_on_gpu(unit_vectors):
         for a, b in v["cases"]:
             assert c.correct(a.encode()).decode() == b, v["name"]
             ran += 1
-    assert ran >= 17
+    assert ran >= 80
 
 
 @pytest.mark.parametrize("group", ["16", "32", "64"])
@@ -180,6 +180,35 @@ def test_one_raw_fasta_fixture_set(raw_reads, solid_fixture_bytes, group, monkey
     if group == "16":
         st = chain.last_stats()
         assert st["probes"] > 0 and st["rounds"] > 0
+
+
+@pytest.mark.parametrize("method", ["two", "graph", "gap_size"])
+@pytest.mark.parametrize("group", ["16", "64"])
+def test_method_raw_fasta_fixture_set(raw_reads, solid_fixture_bytes, method, group, monkeypatch):
+    """every corrector on the reference's integration data, forward + reverse, vs the oracle."""
+    monkeypatch.setenv("BRX_GROUP", group)
+    gs = br_amd.Pcon.from_pcon_solid(solid_fixture_bytes)
+    os_ = O.Solid.from_bytes(solid_fixture_bytes)
+    om = O.build_methods(os_, [method], 5, 7)
+    chain = br_amd.Chain(gs, [(method, 5, 7)], two_side=False)
+    got = chain.correct_reads(raw_reads)
+    changed = 0
+    for r, g in zip(raw_reads, got):
+        assert g == O.correct_record(om, r, False)
+        changed += g != r
+    assert changed > 100
+
+
+def test_default_like_chain(raw_reads, solid_fixture_bytes):
+    """several methods chained in the reference's default order (minus greedy), src/cli.rs:121-131"""
+    gs = br_amd.Pcon.from_pcon_solid(solid_fixture_bytes)
+    os_ = O.Solid.from_bytes(solid_fixture_bytes)
+    names = ["one", "two", "graph", "gap_size"]
+    om = O.build_methods(os_, names, 5, 7)
+    reads = raw_reads[:80]
+    got = br_amd.Chain(gs, [(m, 5, 7) for m in names], two_side=False).correct_reads(reads)
+    for r, g in zip(reads, got):
+        assert g == O.correct_record(om, r, False)
 
 
 def test_one_chained_methods(raw_reads, solid_fixture_bytes):
