@@ -40,7 +40,7 @@ int upload_batch(const uint8_t *bases, const uint64_t *offsets, uint32_t n_reads
 namespace {
 
 // control block layout (u64 words)
-enum { CTL_WORK = 0, CTL_OVERFLOW = 1, CTL_ROUNDS = 2, CTL_PROBES = 3, CTL_TRIGGERS = 4, CTL_FIXES = 5, CTL_TOTAL = 6, CTL_PATHOVF = 7, CTL_N = 8 };
+enum { CTL_WORK = 0, CTL_OVERFLOW = 1, CTL_ROUNDS = 2, CTL_PROBES = 3, CTL_TRIGGERS = 4, CTL_FIXES = 5, CTL_TOTAL = 6, CTL_PATHOVF = 7, CTL_NONTERM = 8, CTL_N = 16 };
 
 struct PassParams {
     const uint32_t *bits;
@@ -61,6 +61,10 @@ struct PassParams {
     // graph walks (Graph, GapSize): per-group list of visited k-mers, maxpath entries each
     uint64_t *path_k;
     uint32_t maxpath;
+    // greedy (greedy.rs): max_search and the per-group LDS carve-up for the alignment
+    int max_search;
+    uint32_t g_dim;       // max (m+1), (n+1) of the DP = k + max_search + 2
+    uint32_t g_lds_bytes; // bytes of dynamic LDS per group
 };
 
 __device__ __forceinline__ uint64_t slot_of(uint64_t o, uint64_t r, uint32_t slack)
@@ -74,7 +78,7 @@ __device__ __forceinline__ bool probe(const uint32_t *__restrict__ bits, uint64_
     return (bits[h >> 5] >> (h & 31u)) & 1u;
 }
 
-enum { ST_INIT = 0, ST_SCAN, ST_ERRLEN, ST_ALTS, ST_SCEN, ST_MORE, ST_WALK, ST_T1, ST_TSCORE, ST_TMORE };
+enum { ST_INIT = 0, ST_SCAN, ST_ERRLEN, ST_ALTS, ST_SCEN, ST_MORE, ST_WALK, ST_T1, ST_TSCORE, ST_TMORE, ST_GFOLLOW, ST_GVALID };
 enum { MODE_ONE = 0, MODE_GRAPH = 1, MODE_INSSUB = 2, MODE_TWO = 3 };
 
 // ---- ScenarioTwo (src/correct/exist/two.rs:34-328), ids in declaration order ---------------------
@@ -159,6 +163,154 @@ __device__ __forceinline__ uint32_t two_correct(const TwoCtx &t, int sc, uint64_
     }
 }
 
+// ---- bio 1.6.0 alignment::pairwise::Aligner::global for Greedy (greedy.rs:56-89) ------------------
+// Affine gaps (open -1, extend -1), match +1 / mismatch -1, no clipping; `>`-only updates in the
+// order match/subst, ins, del; traceback through per-layer back pointers; Ins consumes x, Del y.
+// Restated from the crate's published algorithm (source not in the container; tie-breaks unpinned,
+// SURVEY H3) -- the same restatement as oracle/br_oracle.c:bio_global, laid out as a systolic
+// anti-diagonal sweep: lane l of the group owns DP row band*G+l+1, row values travel to the next
+// lane by shuffle, the back-pointer matrix lives in LDS.
+enum { TBV_START = 0, TBV_INS = 1, TBV_DEL = 2, TBV_SUBST = 3, TBV_MATCH = 4, TBV_XCLIP = 5 };
+enum { OPV_MATCH = 0, OPV_SUBST = 1, OPV_DEL = 2, OPV_INS = 3 };
+constexpr int BIO_MIN = -858993459;
+
+struct GreedyLds {
+    uint8_t *x, *y, *ops, *bT; // x: before+read, y: before+path, ops: traceback (reversed), bT: band boundary tb_s
+    int *bS, *bI;              // band boundary scores
+    uint16_t *tb;              // (m+1) x (n+1) back pointers: s | i<<3 | d<<6
+};
+
+__device__ __forceinline__ GreedyLds greedy_carve(uint8_t *base, uint32_t dim)
+{
+    // dim = max row/column count; all regions 16-byte aligned
+    const uint32_t a = (dim + 15u) & ~15u;
+    GreedyLds L;
+    L.x = base;
+    L.y = base + a;
+    L.ops = base + 2 * a;          // 2*a bytes
+    L.bT = base + 4 * a;
+    L.bS = (int *)(base + 5 * a);  // 4*a bytes
+    L.bI = (int *)(base + 9 * a);  // 4*a bytes
+    L.tb = (uint16_t *)(base + 13 * a);
+    return L;
+}
+
+__host__ __device__ inline uint32_t greedy_lds_bytes(uint32_t dim)
+{
+    const uint32_t a = (dim + 15u) & ~15u;
+    return 13u * a + ((2u * dim * dim + 15u) & ~15u);
+}
+
+template <int G>
+__device__ bool greedy_align(const GreedyLds &L, int gl, int m, int n, int nb, int &off_out)
+{
+    const int go = -1, ge = -1;
+    const int W = m + 1;
+    for (int band = 0; band * G < m; band++) {
+        const int row = band * G + gl + 1;
+        const bool arow = row <= m;
+        const uint8_t pch = arow ? L.x[row - 1] : (uint8_t)0;
+        int S_cur = go + ge * row, I_cur = S_cur, D_cur = BIO_MIN, S_prev1 = S_cur, tbs_cur = TBV_INS; // column 0
+        const bool last_lane = (gl == G - 1);
+        const bool more = (band + 1) * G < m;
+        for (int t = 0; t < n + G - 1; t++) {
+            int upS = __shfl_up(S_cur, 1, G), upI = __shfl_up(I_cur, 1, G);
+            int upT = __shfl_up(tbs_cur, 1, G), upS1 = __shfl_up(S_prev1, 1, G);
+            const int j = t - gl + 1;
+            const bool act = arow && j >= 1 && j <= n;
+            if (act) {
+                if (gl == 0) {
+                    if (band == 0) { // DP row 0
+                        upS = go + ge * j;
+                        upI = BIO_MIN;
+                        upT = TBV_DEL;
+                        upS1 = (j == 1) ? 0 : go + ge * (j - 1);
+                    } else {
+                        upS = L.bS[j];
+                        upI = L.bI[j];
+                        upT = L.bT[j];
+                        upS1 = L.bS[j - 1];
+                    }
+                }
+                const uint8_t q = L.y[j - 1];
+                const int m_score = upS1 + (pch == q ? 1 : -1);
+                int bestI, tbi, bestD, tbd;
+                const int i_score = upI + ge, s_score = upS + go + ge;
+                if (i_score > s_score) { bestI = i_score; tbi = TBV_INS; } else { bestI = s_score; tbi = upT; }
+                const int d_score = D_cur + ge, s2 = S_cur + go + ge;
+                if (d_score > s2) { bestD = d_score; tbd = TBV_DEL; } else { bestD = s2; tbd = tbs_cur; }
+                int bestS = BIO_MIN, tbs = TBV_XCLIP;
+                if (m_score > bestS) { bestS = m_score; tbs = (pch == q) ? TBV_MATCH : TBV_SUBST; }
+                if (bestI > bestS) { bestS = bestI; tbs = TBV_INS; }
+                if (bestD > bestS) { bestS = bestD; tbs = TBV_DEL; }
+                S_prev1 = S_cur;
+                S_cur = bestS;
+                I_cur = bestI;
+                D_cur = bestD;
+                tbs_cur = tbs;
+                L.tb[j * W + row] = (uint16_t)(tbs | (tbi << 3) | (tbd << 6));
+                if (last_lane && more) {
+                    L.bS[j] = bestS;
+                    L.bI[j] = bestI;
+                    L.bT[j] = (uint8_t)tbs;
+                }
+            }
+        }
+        if (last_lane && more)
+            L.bS[0] = go + ge * row;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+
+    // traceback from (m, n); every lane walks the same pointers (LDS broadcast reads)
+    auto tbS = [&](int i, int j) -> int {
+        if (i == 0) return j == 0 ? TBV_START : TBV_DEL;
+        if (j == 0) return TBV_INS;
+        return L.tb[j * W + i] & 7;
+    };
+    auto tbI = [&](int i, int j) -> int {
+        if (j == 0) return i == 1 ? TBV_START : TBV_INS;
+        return (L.tb[j * W + i] >> 3) & 7; // i >= 1 whenever the Ins layer is entered
+    };
+    auto tbD = [&](int i, int j) -> int {
+        if (i == 0) return j == 1 ? TBV_START : TBV_DEL;
+        return (L.tb[j * W + i] >> 6) & 7;
+    };
+    int i = m, j = n, nops = 0;
+    int layer = tbS(i, j);
+    while (nops < m + n + 2) {
+        int next, op;
+        if (layer == TBV_INS) { op = OPV_INS; next = tbI(i, j); i--; }
+        else if (layer == TBV_DEL) { op = OPV_DEL; next = tbD(i, j); j--; }
+        else if (layer == TBV_MATCH || layer == TBV_SUBST) { op = (layer == TBV_MATCH) ? OPV_MATCH : OPV_SUBST; next = tbS(i - 1, j - 1); i--; j--; }
+        else break;
+        if (gl == 0)
+            L.ops[nops] = (uint8_t)op;
+        nops++;
+        layer = next;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    // operations[before_seq.len()..].windows(2), greedy.rs:67-86 (ops are stored back to front)
+    int offset = 0;
+    for (int w = nb; w + 1 < nops; w++) {
+        const int a = L.ops[nops - 1 - w], b = L.ops[nops - 2 - w];
+        if (a == OPV_DEL) offset -= 1;
+        else if (a == OPV_INS) offset += 1;
+        if (a == OPV_MATCH && b == OPV_MATCH) {
+            int oc = 0;
+            for (int e = 0; e < nops; e++) {
+                const int op = L.ops[e];
+                if (op == OPV_DEL) oc -= 1;
+                else if (op == OPV_INS) oc += 1;
+                else break;
+            }
+            off_out = offset - oc;
+            return true;
+        }
+    }
+    return false;
+}
+
 template <int G, int M>
 __global__ __launch_bounds__(256) void correct_kernel(PassParams p)
 {
@@ -166,6 +318,9 @@ __global__ __launch_bounds__(256) void correct_kernel(PassParams p)
     constexpr bool HAS_ONE = (M == BRX_ONE || M == BRX_GAP_SIZE);
     constexpr bool HAS_WALK = HAS_ERRLEN;
     constexpr bool HAS_TWO = (M == BRX_TWO);
+    constexpr bool HAS_GREEDY = (M == BRX_GREEDY);
+    constexpr bool HAS_PATH = HAS_WALK || HAS_GREEDY;
+    extern __shared__ __attribute__((aligned(16))) uint8_t dyn_lds[];
 
     const int lane = threadIdx.x & 63;
     const int gl = lane & (G - 1);
@@ -175,7 +330,10 @@ __global__ __launch_bounds__(256) void correct_kernel(PassParams p)
     const uint32_t c = (uint32_t)p.c;
     const uint64_t mask = kmask(k);
     const uint32_t gid = blockIdx.x * (256 / G) + threadIdx.x / G; // global group index (path scratch slot)
-    unsigned long long *path = HAS_WALK ? (unsigned long long *)p.path_k + (uint64_t)gid * p.maxpath : nullptr;
+    unsigned long long *path = HAS_PATH ? (unsigned long long *)p.path_k + (uint64_t)gid * p.maxpath : nullptr;
+    GreedyLds gL = {};
+    if (HAS_GREEDY)
+        gL = greedy_carve(dyn_lds + (size_t)(threadIdx.x / G) * p.g_lds_bytes, p.g_dim);
 
     // group-uniform state (replicated in every lane of the group)
     uint32_t r = 0, n = 0, cap = 0, i = 0, olen = 0;
@@ -191,34 +349,48 @@ __global__ __launch_bounds__(256) void correct_kernel(PassParams p)
     uint64_t fc = 0, ek = 0, wk = 0;
     TwoCtx tw = {0, 0, 0};
     uint32_t tvalid = 0;
+    // greedy state: iteration, path length in bases, alignment offset
+    uint32_t git = 0, gnl = 0, steps = 0;
+    int goff = 0;
     // statistics
     uint32_t n_rounds = 0, n_probes = 0, n_trig = 0, n_fix = 0;
 
     auto fetch = [&]() {
-        unsigned long long w = 0;
-        if (gl == 0)
-            w = atomicAdd(p.ctrl + CTL_WORK, 1ull);
-        w = __shfl(w, gshift);
-        if (w >= (unsigned long long)p.n_reads) {
-            have = false;
+        for (;;) {
+            unsigned long long w = 0;
+            if (gl == 0)
+                w = atomicAdd(p.ctrl + CTL_WORK, 1ull);
+            w = __shfl(w, gshift);
+            if (w >= (unsigned long long)p.n_reads) {
+                have = false;
+                return;
+            }
+            have = true;
+            r = (uint32_t)w;
+            const uint64_t o0 = p.offsets[r], o1 = p.offsets[r + 1];
+            if (p.in_staged) {
+                in = p.in + slot_of(o0, r, p.slack);
+                n = p.in_lens[r];
+                if (n == 0xffffffffu) {
+                    // an earlier pass of this attempt gave up on this read (slot or walk-list
+                    // overflow): keep it poisoned; the host redoes the batch with more workspace
+                    if (gl == 0)
+                        p.out_lens[r] = 0xffffffffu;
+                    continue;
+                }
+            } else {
+                in = p.in + o0;
+                n = (uint32_t)(o1 - o0);
+            }
+            const uint64_t s0 = slot_of(o0, r, p.slack), s1 = slot_of(o1, (uint64_t)r + 1, p.slack);
+            out = p.out + s0;
+            cap = (uint32_t)(s1 - s0);
+            st = ST_INIT;
+            i = 0;
+            olen = 0;
+            steps = 0;
             return;
         }
-        have = true;
-        r = (uint32_t)w;
-        const uint64_t o0 = p.offsets[r], o1 = p.offsets[r + 1];
-        if (p.in_staged) {
-            in = p.in + slot_of(o0, r, p.slack);
-            n = p.in_lens[r];
-        } else {
-            in = p.in + o0;
-            n = (uint32_t)(o1 - o0);
-        }
-        const uint64_t s0 = slot_of(o0, r, p.slack), s1 = slot_of(o1, (uint64_t)r + 1, p.slack);
-        out = p.out + s0;
-        cap = (uint32_t)(s1 - s0);
-        st = ST_INIT;
-        i = 0;
-        olen = 0;
     };
     auto ld = [&](uint32_t j) -> uint8_t { return in[p.flip ? (n - 1u - j) : j]; };
     auto finish = [&]() {
@@ -230,6 +402,13 @@ __global__ __launch_bounds__(256) void correct_kernel(PassParams p)
         if (gl == 0) {
             p.out_lens[r] = 0xffffffffu;
             atomicAdd(p.ctrl + CTL_OVERFLOW, 1ull);
+        }
+        fetch();
+    };
+    auto nonterminating = [&]() {
+        if (gl == 0) {
+            p.out_lens[r] = 0xffffffffu;
+            atomicAdd(p.ctrl + CTL_NONTERM, 1ull);
         }
         fetch();
     };
@@ -367,7 +546,22 @@ __global__ __launch_bounds__(256) void correct_kernel(PassParams p)
                         do_probe = true;
                     }
                 }
+            } else if (HAS_GREEDY && st == ST_GFOLLOW) {
+                do_probe = gl < 4; // follow_graph -> next_nucs, greedy.rs:91-102
+                pk = add_nuc(wk, (uint64_t)gl, mask);
+            } else if (HAS_GREEDY && st == ST_GVALID) {
+                // check_next_kmers, greedy.rs:104-117
+                const uint32_t rem2 = n - i - git;
+                const uint32_t e = sub * G + (uint32_t)gl;
+                if (rem2 >= c && e < c) {
+                    pk = wk;
+                    for (uint32_t q = 0; q <= e; q++)
+                        pk = add_nuc(pk, nuc2bit(ld(i + git + q)), mask);
+                    do_probe = true;
+                }
             }
+            if (HAS_GREEDY && ++steps > (1u << 24))
+                do_probe = false;
         }
 
         // ---------------- phase 2: one probe per lane, whole wave at once ---------------------
@@ -503,6 +697,23 @@ __global__ __launch_bounds__(256) void correct_kernel(PassParams p)
                         npath = 1;
                         wk = corr;
                         st = ST_WALK;
+                    } else if (HAS_GREEDY) {
+                        // greedy.rs:135-145: before = kmer2seq(kmer >> 2, k-1); path = [alt]; viewed = {corr}
+                        const uint64_t pre = kmer >> 2;
+                        for (int j = gl; j < k - 1; j += G) {
+                            const uint8_t b = bit2nuc((pre >> (2 * (k - 2 - j))) & 3ull);
+                            gL.x[j] = b;
+                            gL.y[j] = b;
+                        }
+                        if (gl == 0) {
+                            gL.y[k - 1] = bit2nuc(corr & 3ull);
+                            __hip_atomic_store(path, (unsigned long long)corr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                        gnl = 1;
+                        npath = 1;
+                        wk = corr;
+                        git = 0;
+                        st = ST_GFOLLOW;
                     } else if (HAS_TWO) {
                         uint32_t s4 = 0;
                         for (uint32_t j = 0; j < 4 && j < rem; j++)
@@ -621,6 +832,84 @@ __global__ __launch_bounds__(256) void correct_kernel(PassParams p)
                     apply_t = __ffs(keep) - 1;
                 else
                     fail = true;
+            } else if (HAS_GREEDY && st == ST_GFOLLOW) {
+                const uint32_t am = (uint32_t)(gmask & 0xfull);
+                if (__popc(am) == 1) { // follow_graph succeeded: extend the path
+                    const uint64_t a = (uint64_t)(__ffs(am) - 1);
+                    if (gl == 0)
+                        gL.y[k - 1 + (int)gnl] = bit2nuc(a);
+                    gnl++;
+                    wk = add_nuc(wk, a, mask);
+                }
+                bool hit = false; // greedy.rs:153-157 (a failed follow leaves kmer in the set -> None)
+                for (uint32_t j = gl; j < npath; j += G)
+                    hit |= __hip_atomic_load(path + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == wk;
+                const uint64_t anyhit = (__ballot(hit) >> gshift) & GM;
+                const uint32_t rem = n - i;
+                if (anyhit || rem < git) { // greedy.rs:159-161
+                    fail = true;
+                } else if (npath >= p.maxpath) {
+                    path_overflow();
+                } else {
+                    if (gl == 0) {
+                        __hip_atomic_store(path + npath, (unsigned long long)wk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (git >= 1u)
+                            gL.x[k - 1 + (int)git - 1] = ld(i + git - 1u);
+                    }
+                    npath++;
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    int off = 0;
+                    const bool found = greedy_align<G>(gL, gl, k - 1 + (int)git, k - 1 + (int)gnl, k - 1, off);
+                    if (found) {
+                        goff = off;
+                        sub = 0;
+                        st = ST_GVALID;
+                    } else if (++git >= (uint32_t)p.max_search) {
+                        fail = true;
+                    }
+                }
+            } else if (HAS_GREEDY && st == ST_GVALID) {
+                const uint32_t rem2 = n - i - git;
+                bool ok = rem2 >= c, done = false;
+                if (ok && c > 0u) {
+                    const uint32_t leftc = c - sub * G;
+                    const uint32_t nv = leftc < (uint32_t)G ? leftc : (uint32_t)G;
+                    const uint64_t vm = (nv >= 64u) ? ~0ull : ((1ull << nv) - 1ull);
+                    ok = (gmask & vm) == vm;
+                    sub++;
+                    done = ok && sub * G >= c;
+                } else if (ok) {
+                    done = true;
+                }
+                if (!ok) {
+                    st = ST_GFOLLOW;
+                    if (++git >= (uint32_t)p.max_search)
+                        fail = true;
+                } else if (done) {
+                    // greedy.rs:165-167: offset = (local_corr.len() as i64 + off) as usize, wrapping add
+                    if (olen + gnl + 1u > cap) {
+                        overflow();
+                    } else {
+                        for (uint32_t j = gl; j < gnl; j += G)
+                            out[olen + j] = gL.y[k - 1 + (int)j];
+                        olen += gnl;
+                        kmer = wk;
+                        prev = true;
+                        const long long ni = (long long)i + (long long)gnl + (long long)goff;
+                        i = (ni < 0 || ni > (long long)n) ? n : (uint32_t)ni;
+                        n_fix += (gl == 0);
+                        if (i >= n)
+                            finish();
+                        else
+                            st = ST_SCAN;
+                    }
+                }
+            }
+            if (HAS_GREEDY && have && steps > (1u << 24)) {
+                fail = false;
+                apply_s = apply_t = -1;
+                apply_path = false;
+                nonterminating();
             }
 
             if (fail) {
@@ -785,31 +1074,59 @@ uint32_t pass_blocks(uint32_t n_reads, int G)
 }
 
 template <int M>
-void launch_method(const PassParams &p, int G, uint32_t blocks, hipStream_t s)
+int launch_method(const PassParams &p, int G, uint32_t blocks, size_t lds, hipStream_t s)
 {
+    if (lds > 64 * 1024) {
+        const void *fn = G == 16 ? (const void *)correct_kernel<16, M>
+                       : G == 32 ? (const void *)correct_kernel<32, M> : (const void *)correct_kernel<64, M>;
+        BRX_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
     if (G == 16)
-        correct_kernel<16, M><<<blocks, 256, 0, s>>>(p);
+        correct_kernel<16, M><<<blocks, 256, lds, s>>>(p);
     else if (G == 32)
-        correct_kernel<32, M><<<blocks, 256, 0, s>>>(p);
+        correct_kernel<32, M><<<blocks, 256, lds, s>>>(p);
     else
-        correct_kernel<64, M><<<blocks, 256, 0, s>>>(p);
+        correct_kernel<64, M><<<blocks, 256, lds, s>>>(p);
+    return BRX_OK;
 }
 
-int launch_pass(const PassParams &p, int method, int G, hipStream_t s)
+// Greedy needs LDS for the alignment back pointers: pick the narrowest group width that fits
+int greedy_group(int G, int k, int max_search, uint32_t *dim, uint32_t *per_group)
 {
-    const uint32_t blocks = pass_blocks(p.n_reads, G);
+    *dim = (uint32_t)(k + max_search + 2);
+    *per_group = greedy_lds_bytes(*dim);
+    for (; G <= 64; G *= 2)
+        if ((uint64_t)(256 / G) * *per_group <= 160u * 1024u)
+            return G;
+    return 0;
+}
+
+int launch_pass(PassParams p, const brx_method_t &md, int G, hipStream_t s)
+{
     static const char *names[5] = {"correct_pass", "correct_pass_two", "correct_pass_graph", "correct_pass_greedy",
                                    "correct_pass_gap_size"};
+    const int method = md.method;
+    size_t lds = 0;
+    p.max_search = md.max_search;
+    p.g_dim = 0;
+    p.g_lds_bytes = 0;
     if (method == BRX_GREEDY) {
-        set_error("correction method greedy not implemented on the GPU path yet");
-        return BRX_ERR_UNSUPPORTED;
+        G = greedy_group(G, p.k, md.max_search, &p.g_dim, &p.g_lds_bytes);
+        if (!G) {
+            set_error("greedy: k=%d with max_search=%d needs a %u x %u alignment table that does not fit LDS", p.k,
+                      (int)md.max_search, p.g_dim, p.g_dim);
+            return BRX_ERR_UNSUPPORTED;
+        }
+        lds = (size_t)(256 / G) * p.g_lds_bytes;
     }
+    const uint32_t blocks = pass_blocks(p.n_reads, G);
     KernelTimer t(names[method], s);
     switch (method) {
-    case BRX_ONE: launch_method<BRX_ONE>(p, G, blocks, s); break;
-    case BRX_TWO: launch_method<BRX_TWO>(p, G, blocks, s); break;
-    case BRX_GRAPH: launch_method<BRX_GRAPH>(p, G, blocks, s); break;
-    case BRX_GAP_SIZE: launch_method<BRX_GAP_SIZE>(p, G, blocks, s); break;
+    case BRX_ONE: BRX_TRY(launch_method<BRX_ONE>(p, G, blocks, lds, s)); break;
+    case BRX_TWO: BRX_TRY(launch_method<BRX_TWO>(p, G, blocks, lds, s)); break;
+    case BRX_GRAPH: BRX_TRY(launch_method<BRX_GRAPH>(p, G, blocks, lds, s)); break;
+    case BRX_GREEDY: BRX_TRY(launch_method<BRX_GREEDY>(p, G, blocks, lds, s)); break;
+    case BRX_GAP_SIZE: BRX_TRY(launch_method<BRX_GAP_SIZE>(p, G, blocks, lds, s)); break;
     default: break;
     }
     BRX_HIP(hipGetLastError());
@@ -921,7 +1238,8 @@ int brx_chain_correct_batch_device(brx_chain_t *ch, const uint8_t *d_bases, cons
     const int G = group_width();
     bool needs_path = false;
     for (int m = 0; m < n_methods; m++)
-        needs_path |= (ch->methods[m].method == BRX_GRAPH || ch->methods[m].method == BRX_GAP_SIZE);
+        needs_path |= (ch->methods[m].method == BRX_GRAPH || ch->methods[m].method == BRX_GAP_SIZE ||
+                       ch->methods[m].method == BRX_GREEDY);
     uint32_t maxpath = 512;
 
     for (uint32_t slack = 1, attempt = 0;; attempt++) {
@@ -930,7 +1248,7 @@ int brx_chain_correct_batch_device(brx_chain_t *ch, const uint8_t *d_bases, cons
             return BRX_ERR_OVERFLOW;
         }
         if (needs_path) {
-            const uint64_t n_groups = (uint64_t)pass_blocks(n_reads, G) * (256u / (uint32_t)G);
+            const uint64_t n_groups = (uint64_t)MAX_BLOCKS * 16u; // upper bound over every group width
             BRX_TRY(ensure((void **)&ch->d_path, &ch->path_bytes, n_groups * maxpath * 8ull));
         }
         const uint64_t stage_need = total_bases + (total_bases >> 2) * slack + 64ull * ((uint64_t)n_reads + 1) + 64;
@@ -971,7 +1289,7 @@ int brx_chain_correct_batch_device(brx_chain_t *ch, const uint8_t *d_bases, cons
                 p.path_k = ch->d_path;
                 p.maxpath = maxpath;
                 BRX_HIP(hipMemsetAsync(ch->d_ctrl + CTL_WORK, 0, 8, s));
-                BRX_TRY(launch_pass(p, ch->methods[m].method, G, s));
+                BRX_TRY(launch_pass(p, ch->methods[m], G, s));
                 cur = ch->d_stage[pp];
                 cur_lens = ch->d_lens[pp];
                 cur_staged = 1;
@@ -987,6 +1305,11 @@ int brx_chain_correct_batch_device(brx_chain_t *ch, const uint8_t *d_bases, cons
         BRX_HIP(hipMemcpyAsync(ch->h_ctrl, ch->d_ctrl, CTL_N * 8, hipMemcpyDeviceToHost, s));
         BRX_HIP(hipStreamSynchronize(s));
         stats[4] = attempt;
+        if (ch->h_ctrl[CTL_NONTERM] != 0) {
+            set_error("%llu read(s): the scan does not terminate (greedy moved the read cursor backwards for ever; "
+                      "the reference spins on such input)", (unsigned long long)ch->h_ctrl[CTL_NONTERM]);
+            return BRX_ERR_UNSUPPORTED;
+        }
         if (ch->h_ctrl[CTL_OVERFLOW] != 0 || ch->h_ctrl[CTL_PATHOVF] != 0) {
             // some read outgrew its output slot / a graph walk outgrew its visited list: redo the
             // batch on the GPU with a larger workspace (never on the CPU)

@@ -15,7 +15,7 @@ from oracle import oracle as O
 
 pytestmark = pytest.mark.gpu
 
-IMPLEMENTED = {"one", "two", "graph", "gap_size"}  # methods with a GPU kernel; the others must fail loudly
+IMPLEMENTED = {"one", "two", "graph", "greedy", "gap_size"}  # methods with a GPU kernel; the others must fail loudly
 
 
 def _oracle_set(v):
@@ -182,7 +182,7 @@ def test_one_raw_fasta_fixture_set(raw_reads, solid_fixture_bytes, group, monkey
         assert st["probes"] > 0 and st["rounds"] > 0
 
 
-@pytest.mark.parametrize("method", ["two", "graph", "gap_size"])
+@pytest.mark.parametrize("method", ["two", "graph", "gap_size", "greedy"])
 @pytest.mark.parametrize("group", ["16", "64"])
 def test_method_raw_fasta_fixture_set(raw_reads, solid_fixture_bytes, method, group, monkeypatch):
     """every corrector on the reference's integration data, forward + reverse, vs the oracle."""
@@ -200,10 +200,10 @@ def test_method_raw_fasta_fixture_set(raw_reads, solid_fixture_bytes, method, gr
 
 
 def test_default_like_chain(raw_reads, solid_fixture_bytes):
-    """several methods chained in the reference's default order (minus greedy), src/cli.rs:121-131"""
+    """all five methods chained in the reference's default order, src/cli.rs:121-131"""
     gs = br_amd.Pcon.from_pcon_solid(solid_fixture_bytes)
     os_ = O.Solid.from_bytes(solid_fixture_bytes)
-    names = ["one", "two", "graph", "gap_size"]
+    names = ["one", "two", "graph", "greedy", "gap_size"]
     om = O.build_methods(os_, names, 5, 7)
     reads = raw_reads[:80]
     got = br_amd.Chain(gs, [(m, 5, 7) for m in names], two_side=False).correct_reads(reads)
@@ -327,3 +327,55 @@ def test_synthetic_build_and_correct(k):
     assert np.array_equal(out, exp)
     st = chain.last_stats()
     assert st["fixes"] > 0 and st["triggers"] >= st["fixes"]
+
+
+@pytest.mark.parametrize("method", ["one", "two", "graph", "greedy", "gap_size"])
+def test_synthetic_every_method(method):
+    """synthetic reads where most triggers are real isolated errors (lots of positive fixes)."""
+    k, n_reads, read_len = 13, 160, 1500
+    cfg = synth.config(genome_len=n_reads * read_len // 30, read_len=read_len, sub=0.01, ins=0.006, dele=0.006)
+    g = synth.genome_host(cfg)
+    hb, ho = synth.reads_host(cfg, g, 0, n_reads)
+    reads = [hb[int(ho[i]):int(ho[i + 1])].tobytes() for i in range(n_reads)]
+    gs = br_amd.Pcon.from_count(reads, k, 2)
+    ref = O.Solid.from_count(k, O.count_reads(k, reads), 2)
+    assert gs.to_solid_bytes() == ref.to_bytes()
+    om = O.build_methods(ref, [method], 5, 7)
+    chain = br_amd.Chain(gs, [(method, 5, 7)], two_side=False)
+    out, oo = chain.correct_batch(hb, ho)
+    exp, exp_o = O.correct_batch(om, hb, ho, False)
+    assert np.array_equal(oo, exp_o)
+    assert np.array_equal(out, exp)
+    assert om[0].stats()["fixes"] > (50 if method == "greedy" else 200)
+
+
+def test_greedy_parameters(raw_reads, solid_fixture_bytes):
+    gs = br_amd.Pcon.from_pcon_solid(solid_fixture_bytes)
+    os_ = O.Solid.from_bytes(solid_fixture_bytes)
+    reads = raw_reads[:40]
+    for max_search, nbv in [(1, 2), (3, 0), (12, 3), (7, 20)]:
+        om = [O.Corrector(os_, "greedy", nbv, max_search)]
+        got = br_amd.Chain(gs, [("greedy", nbv, max_search)], two_side=False).correct_reads(reads)
+        for r, g in zip(reads, got):
+            assert g == O.correct_record(om, r, False), (max_search, nbv)
+
+
+def test_output_slot_overflow_retry():
+    """a read whose correction grows it far beyond its staging slot (Graph re-inserting a 150-base
+    deletion): the batch is redone on the GPU with a larger slack, result identical to the oracle."""
+    rng = np.random.default_rng(7)
+    k = 15   # large enough that the 3 kb random genome has no branching (k-1)-mers
+    genome = bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=3000).tolist())
+    ref = O.Solid(k)
+    ref.set_seq(genome)
+    gs = br_amd.Pcon.from_pcon_solid(ref.to_bytes())
+    reads = [genome[100:160] + genome[310:370], genome[500:560] + genome[900:960], genome[1000:1400]]
+    for method in ("graph", "gap_size"):
+        om = O.build_methods(ref, [method], 5, 7)
+        chain = br_amd.Chain(gs, [(method, 5, 7)], two_side=True)
+        got = chain.correct_reads(reads)
+        exp = [O.correct_record(om, r, True) for r in reads]
+        assert got == exp
+        if method == "graph":
+            assert got[0] == genome[100:370] and got[1] == genome[500:960]
+            assert chain.last_stats()["overflow_retries"] >= 1
