@@ -62,6 +62,8 @@ struct brx_set {
     uint32_t *d_bits;  // nwords, zero padded
 };
 
+namespace brx { struct PartState; }
+
 struct brx_counter {
     int k;
     int device;
@@ -69,7 +71,8 @@ struct brx_counter {
     // dense: u8 table packed in u32 words (2^(2k-1) bytes, padded to 32 B)
     uint32_t *d_counts;
     uint64_t count_bytes;
-    // sorted: canonical hashes
+    // partitioned strategy (brx_partbuild.hip)
+    brx::PartState *part;
     uint64_t *d_keys;
     uint64_t n_keys, cap_keys;
     hipStream_t stream; // owned, used by host-pointer entry points

@@ -1,0 +1,787 @@
+// Partitioned set build (BRX_COUNT_SORTED): the same bitset as count -> threshold, without the
+// 2^(2k-1)-byte count table.
+//
+// Reference semantics: pcon Counter<u8>::count_fasta + Solid::from_count (src/main.rs:72-115):
+// bit h is set iff min(255, occurrences of canonical hash h) > abundance.
+//
+// Why: random 1-byte RMWs into a 128 GiB table (k=19) run at the chip's random-request ceiling
+// (~50 G requests/s, profiles/r1_probe_bench_calibration.txt) and drag two full passes over the
+// table behind them (zeroing + thresholding).  Scattered 4-byte stores hit the same ceiling.  So
+// the canonical hashes are PARTITIONED by their high bits, MSD-radix style, with streaming passes
+// whose writes are staged through LDS into bucket-contiguous runs, until a bucket's hash range
+// (2^12 hashes) fits a per-wavefront LDS counter array:
+//
+//   hash (2k-1 bits) = [ digit 1 | digit 2 | (digit 3) | low 12 bits ]      digits of <= 9 bits
+//   level l   histogram pass (LDS histogram per tile, non-zero bins flushed with global atomics),
+//             exclusive scan -> child bucket offsets, scatter pass: tile of 4-8 K keys, LDS
+//             histogram + block scan, keys ranked into an LDS staging buffer, one global atomic
+//             per (tile, bucket) reserves the run, runs written out with consecutive lanes on
+//             consecutive addresses.  Level 1 reads the bases (k-mers are re-derived, never stored
+//             whole); the last level writes the low 12 bits as u16.
+//   final     one wavefront per fine bucket: u16 LDS counters (2 per word), bucket offsets fetched
+//             64 at a time and keys two buckets ahead, count -> min(255,.) > abundance -> the
+//             bucket's 512-byte slice of the bitset, written whole (no zeroing pass of the bitset).
+//
+// Order inside a bucket is irrelevant (we only count): no stable ranking, no per-tile prefix
+// matrices.  HBM traffic for k=19: ~30 B per k-mer + one 16 GiB bitset write, instead of 129 B
+// per k-mer + 2 x 128 GiB.
+#include "brx_internal.hpp"
+
+#include <stdlib.h>
+#include <string.h>
+
+namespace brx {
+uint64_t scan_tmp_bytes(uint32_t n);
+int exclusive_scan_lens(const uint32_t *d_lens, uint32_t n, uint64_t *d_tmp, uint64_t *d_out_offsets,
+                        unsigned long long *d_total, hipStream_t s);
+}
+
+using namespace brx;
+
+namespace {
+
+constexpr int F_BITS = 12;      // hashes per fine bucket = 4096 (8 KiB of u16 counters per wave)
+constexpr int MAX_LEVELS = 3;
+constexpr int MAX_DIGIT_BITS = 9;
+
+struct Plan {
+    int k, nbits, nlev;
+    int bits[MAX_LEVELS];        // digit width of each level (may be 0 = pass-through)
+    int rem_in[MAX_LEVELS];      // key bits entering the level
+    uint64_t nchild[MAX_LEVELS]; // number of buckets after the level
+};
+
+Plan make_plan(int k)
+{
+    Plan p;
+    memset(&p, 0, sizeof(p));
+    p.k = k;
+    p.nbits = 2 * k - 1;
+    const int P = p.nbits - F_BITS; // bits to partition away
+    p.nlev = P > 2 * MAX_DIGIT_BITS ? 3 : 2;
+    int left = P, rem = p.nbits;
+    uint64_t nb = 1;
+    for (int l = 0; l < p.nlev; l++) {
+        const int b = (left + (p.nlev - l) - 1) / (p.nlev - l); // spread evenly, larger digits first
+        p.bits[l] = b;
+        p.rem_in[l] = rem;
+        rem -= b;
+        left -= b;
+        nb <<= b;
+        p.nchild[l] = nb;
+    }
+    return p;
+}
+
+// ---- tile tables ------------------------------------------------------------------------------------
+// ntiles[p] = ceil(count_p / tile); counts come from read lengths (level 1) or bucket offsets
+__global__ void tiles_from_reads_kernel(const uint64_t *__restrict__ offsets, uint32_t n_reads, int k, uint32_t tile,
+                                        uint32_t *__restrict__ ntiles)
+{
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_reads)
+        return;
+    const uint64_t len = offsets[r + 1] - offsets[r];
+    const uint64_t nk = len >= (uint64_t)k ? len - (uint64_t)k + 1 : 0;
+    ntiles[r] = (uint32_t)((nk + tile - 1) / tile);
+}
+
+__global__ void tiles_from_offsets_kernel(const uint64_t *__restrict__ poff, uint64_t n_parents, uint32_t tile,
+                                          uint32_t *__restrict__ ntiles)
+{
+    const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_parents)
+        return;
+    const uint64_t n = poff[p + 1] - poff[p];
+    ntiles[p] = (uint32_t)((n + tile - 1) / tile);
+}
+
+// ---- one radix level ----------------------------------------------------------------------------------
+struct LevelArgs {
+    // source: bases (level 1) or u32 keys of the previous level
+    const uint8_t *bases;
+    const uint64_t *offsets;   // read offsets (level 1)
+    const uint32_t *keys_in;
+    const uint64_t *poff;      // parent bucket offsets into keys_in (levels >= 2)
+    uint64_t n_parents;
+    const uint64_t *item_off;  // n_parents + 1: first work item of each parent
+    const uint32_t *item_parent; // per work item: its parent
+    const unsigned long long *n_items; // device scalar = item_off[n_parents]
+    uint32_t tile;             // keys per work item
+    int k;
+    int rem_in, bits;          // digit = (key >> (rem_in - bits))
+    int hier;                  // 1: child bucket = parent * B + digit; 0 (level 1): child = digit
+    uint32_t *hist;            // child counts
+    const uint64_t *coff;      // child offsets (scatter)
+    uint32_t *cursor;          // child fill cursors (scatter)
+    void *keys_out;
+};
+
+// ---- level-1 source: the tile's bases, packed 2 bits each into LDS ----------------------------------
+// word w holds tile-local bases 16w..16w+15, first base in the top bits, so a k-mer is a 2k-bit
+// field of the big-endian bit string.  pack4: ASCII bytes b0..b3 (b0 at the lowest address) ->
+// (c0<<6 | c1<<4 | c2<<2 | c3), c = (b >> 1) & 3.
+__device__ __forceinline__ uint32_t pack4(uint32_t w)
+{
+    uint32_t x = __builtin_bswap32((w >> 1) & 0x03030303u);
+    x |= x >> 6;
+    return (x | (x >> 12)) & 0xffu;
+}
+
+constexpr uint32_t PACK_WORDS_MAX = 8192 / 16 + 4;
+
+// packs bases [b0, b0 + nbases) of `seq` (read length len) into pk[]; out-of-read bases read as A
+__device__ __forceinline__ void pack_tile_bases(const uint8_t *__restrict__ seq, uint64_t len, uint64_t b0, uint32_t nbases,
+                                                uint32_t *__restrict__ pk)
+{
+    const uint32_t nwords = (nbases + 15u) / 16u;
+    for (uint32_t w = threadIdx.x; w < nwords; w += 256) {
+        const uint64_t p = b0 + 16ull * w;
+        uint32_t v[4] = {0, 0, 0, 0};
+        if (p + 16 <= len) {
+            uint4 q;
+            __builtin_memcpy(&q, seq + p, 16); // one (possibly unaligned) global_load_dwordx4
+            v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+        } else {
+            for (uint32_t j = 0; j < 16; j++)
+                if (p + j < len)
+                    v[j >> 2] |= (uint32_t)seq[p + j] << (8u * (j & 3u));
+        }
+        pk[w] = (pack4(v[0]) << 24) | (pack4(v[1]) << 16) | (pack4(v[2]) << 8) | pack4(v[3]);
+    }
+}
+
+// forward k-mer starting at tile-local base `pos`
+__device__ __forceinline__ uint64_t kmer_at(const uint32_t *__restrict__ pk, uint32_t pos, int k)
+{
+    const uint32_t w = pos >> 4, sh = 2u * (pos & 15u);
+    const uint64_t hi = ((uint64_t)pk[w] << 32) | pk[w + 1];
+    const uint64_t lo = pk[w + 2];
+    const uint64_t val = sh ? ((hi << sh) | (lo >> (32u - sh))) : hi;
+    return val >> (64 - 2 * k);
+}
+
+// Visits the keys of one tile: thread t gets the tile-local positions t, t+256, ... (consecutive
+// lanes, consecutive keys).  For level 1 the bases must already be packed in pk[] (prepare_tile).
+template <bool FROM_BASES>
+__device__ __forceinline__ uint32_t prepare_tile(const LevelArgs &a, uint64_t parent, uint64_t tile_in_parent, uint32_t *pk,
+                                                 uint64_t &key_base)
+{
+    if (FROM_BASES) {
+        const uint64_t s = a.offsets[parent];
+        const uint64_t len = a.offsets[parent + 1] - s;
+        const uint64_t nk = len - (uint64_t)a.k + 1; // a parent with tiles has len >= k
+        const uint64_t p0 = tile_in_parent * a.tile;
+        const uint32_t n_here = (uint32_t)((nk - p0 < a.tile) ? nk - p0 : a.tile);
+        pack_tile_bases(a.bases + s, len, p0, n_here + (uint32_t)a.k - 1u + 32u, pk);
+        key_base = 0;
+        return n_here;
+    } else {
+        const uint64_t lo = a.poff[parent] + tile_in_parent * a.tile;
+        const uint64_t hi_p = a.poff[parent + 1];
+        key_base = lo;
+        return (uint32_t)((hi_p - lo < a.tile) ? hi_p - lo : a.tile);
+    }
+}
+
+template <bool FROM_BASES>
+__device__ __forceinline__ uint64_t tile_key(const LevelArgs &a, const uint32_t *pk, uint64_t key_base, uint32_t pos)
+{
+    if (FROM_BASES)
+        return khash(kmer_at(pk, pos, a.k), a.k);
+    return a.keys_in[key_base + pos];
+}
+
+template <bool FROM_BASES>
+__global__ __launch_bounds__(256) void level_hist_kernel(LevelArgs a)
+{
+    extern __shared__ uint32_t lds[]; // hist[B]
+    __shared__ uint32_t pk[FROM_BASES ? PACK_WORDS_MAX : 1];
+    const uint32_t B = 1u << a.bits;
+    const int shift = a.rem_in - a.bits;
+    const unsigned long long n_items = *a.n_items;
+    for (unsigned long long item = blockIdx.x; item < n_items; item += gridDim.x) {
+        const uint64_t parent = a.item_parent[item];
+        for (uint32_t b = threadIdx.x; b < B; b += 256)
+            lds[b] = 0;
+        uint64_t key_base;
+        const uint32_t n_here = prepare_tile<FROM_BASES>(a, parent, item - a.item_off[parent], pk, key_base);
+        __syncthreads();
+        for (uint32_t pos = threadIdx.x; pos < n_here; pos += 256) {
+            const uint64_t key = tile_key<FROM_BASES>(a, pk, key_base, pos);
+            atomicAdd(&lds[(uint32_t)(key >> shift) & (B - 1u)], 1u);
+        }
+        __syncthreads();
+        const uint64_t cbase = a.hier ? parent * B : 0;
+        for (uint32_t b = threadIdx.x; b < B; b += 256) {
+            const uint32_t c = lds[b];
+            if (c)
+                atomicAdd(&a.hist[cbase + b], c);
+        }
+        __syncthreads();
+    }
+}
+
+template <bool FROM_BASES, typename OUT>
+__global__ __launch_bounds__(256) void level_scatter_kernel(LevelArgs a)
+{
+    // LDS: stage_key[T] (u32) | stage_dig[T] (u16) | gbase[B] (u64) | cnt[B] | lofs[B] | lcur[B]
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+    __shared__ uint32_t sh_wsum[4];
+    __shared__ uint32_t pk[FROM_BASES ? PACK_WORDS_MAX : 1];
+    const uint32_t T = a.tile;
+    const uint32_t B = 1u << a.bits;
+    uint32_t *stage_key = (uint32_t *)lds_raw;
+    uint16_t *stage_dig = (uint16_t *)(lds_raw + (size_t)T * 4);
+    unsigned long long *gbase = (unsigned long long *)(lds_raw + (size_t)T * 6);
+    uint32_t *cntv = (uint32_t *)(lds_raw + (size_t)T * 6 + (size_t)B * 8);
+    uint32_t *lofs = cntv + B;
+    uint32_t *lcur = lofs + B;
+    const int shift = a.rem_in - a.bits;
+    const uint32_t child_mask = (shift >= 32) ? 0xffffffffu : ((1u << shift) - 1u);
+    OUT *out = (OUT *)a.keys_out;
+    const unsigned long long n_items = *a.n_items;
+    const uint32_t BPT = (B + 255u) / 256u; // bins per thread in the block scan (1 or 2)
+
+    for (unsigned long long item = blockIdx.x; item < n_items; item += gridDim.x) {
+        const uint64_t parent = a.item_parent[item];
+        for (uint32_t b = threadIdx.x; b < B; b += 256)
+            cntv[b] = 0;
+        uint64_t key_base;
+        const uint32_t n_here = prepare_tile<FROM_BASES>(a, parent, item - a.item_off[parent], pk, key_base);
+        __syncthreads();
+        // sweep 1: digits -> LDS histogram; the digit (and the stripped key) is parked in the staging
+        // buffer at the key's own position so that sweep 2 does not have to re-derive it
+        for (uint32_t pos = threadIdx.x; pos < n_here; pos += 256) {
+            const uint64_t key = tile_key<FROM_BASES>(a, pk, key_base, pos);
+            const uint32_t d = (uint32_t)(key >> shift) & (B - 1u);
+            atomicAdd(&cntv[d], 1u);
+        }
+        __syncthreads();
+        // block exclusive scan of cntv[0..B) -> lofs; thread t owns bins [t*BPT, t*BPT+BPT)
+        {
+            uint32_t mine = 0;
+            for (uint32_t q = 0; q < BPT; q++) {
+                const uint32_t b = threadIdx.x * BPT + q;
+                if (b < B)
+                    mine += cntv[b];
+            }
+            uint32_t incl = mine;
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t t = __shfl_up(incl, d);
+                if ((threadIdx.x & 63) >= (unsigned)d)
+                    incl += t;
+            }
+            if ((threadIdx.x & 63) == 63)
+                sh_wsum[threadIdx.x >> 6] = incl;
+            __syncthreads();
+            uint32_t wbase = 0;
+            for (uint32_t w = 0; w < (threadIdx.x >> 6); w++)
+                wbase += sh_wsum[w];
+            uint32_t run = wbase + incl - mine;
+            const uint64_t cbase = a.hier ? parent * B : 0;
+            for (uint32_t q = 0; q < BPT; q++) {
+                const uint32_t b = threadIdx.x * BPT + q;
+                if (b < B) {
+                    const uint32_t c = cntv[b];
+                    lofs[b] = run;
+                    lcur[b] = run;
+                    // reserve the run inside child bucket (cbase + b)
+                    gbase[b] = c ? a.coff[cbase + b] + atomicAdd(&a.cursor[cbase + b], c) : 0ull;
+                    run += c;
+                }
+            }
+        }
+        __syncthreads();
+        // sweep 2: rank every key inside its bucket, park it in the staging buffer
+        for (uint32_t pos = threadIdx.x; pos < n_here; pos += 256) {
+            const uint64_t key = tile_key<FROM_BASES>(a, pk, key_base, pos);
+            const uint32_t d = (uint32_t)(key >> shift) & (B - 1u);
+            const uint32_t slot = atomicAdd(&lcur[d], 1u);
+            stage_key[slot] = (uint32_t)key & child_mask;
+            stage_dig[slot] = (uint16_t)d;
+        }
+        __syncthreads();
+        // write-out: consecutive lanes, consecutive addresses inside each bucket's run
+        for (uint32_t idx = threadIdx.x; idx < n_here; idx += 256) {
+            const uint32_t d = stage_dig[idx];
+            out[gbase[d] + (idx - lofs[d])] = (OUT)stage_key[idx];
+        }
+        __syncthreads();
+    }
+}
+
+// item -> parent map (replaces a binary search per work item)
+__global__ void fill_item_parent_kernel(const uint64_t *__restrict__ item_off, uint64_t n_parents,
+                                        uint32_t *__restrict__ item_parent)
+{
+    const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_parents)
+        return;
+    const uint64_t lo = item_off[p], hi = item_off[p + 1];
+    for (uint64_t i = lo; i < hi; i++)
+        item_parent[i] = (uint32_t)p;
+}
+
+// ---- final stage: one wavefront per fine bucket (4096 hashes) -----------------------------------------
+constexpr int P3_WAVES = 4;
+constexpr uint32_t F_SIZE = 1u << F_BITS;   // 4096 hashes
+constexpr uint32_t CNT_WORDS = F_SIZE / 2;  // u16 counters, 2 per word: hash h -> half (h>>11) of word (h & 2047)
+constexpr uint32_t BIT_WORDS = F_SIZE / 32; // 128
+constexpr uint32_t CHUNK_MAX = 65000;       // keys counted between two clamps (the u16 halves must not carry)
+
+constexpr uint32_t STAGE_KEYS = 2048;       // keys of a group of buckets staged in LDS per wave
+
+__global__ __launch_bounds__(64 * P3_WAVES) void final_count_kernel(const uint16_t *__restrict__ keys,
+                                                                     const uint64_t *__restrict__ off, uint64_t n_buckets,
+                                                                     uint32_t abundance, uint32_t *__restrict__ bits)
+{
+    __shared__ uint32_t cnt_all[P3_WAVES][CNT_WORDS];
+    __shared__ uint32_t bit_all[P3_WAVES][BIT_WORDS];
+    __shared__ __attribute__((aligned(8))) uint16_t stage_all[P3_WAVES][STAGE_KEYS + 8];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    uint32_t *cnt = cnt_all[wave];
+    uint32_t *bmp = bit_all[wave];
+    uint16_t *stage = stage_all[wave];
+    for (uint32_t w = lane; w < CNT_WORDS; w += 64)
+        cnt[w] = 0;
+    for (uint32_t w = lane; w < BIT_WORDS; w += 64)
+        bmp[w] = 0;
+    asm volatile("" ::: "memory");
+
+    // consecutive buckets go to one wave, so its key stream is contiguous
+    const uint64_t n_waves = (uint64_t)gridDim.x * P3_WAVES;
+    const uint64_t wid = (uint64_t)blockIdx.x * P3_WAVES + wave;
+    const uint64_t per = (n_buckets + n_waves - 1) / n_waves;
+    const uint64_t b_lo = wid * per;
+    const uint64_t b_hi = (b_lo + per < n_buckets) ? b_lo + per : n_buckets;
+
+    // groups of up to 63 buckets: one coalesced load brings the 64 offsets that delimit them, one
+    // batch of coalesced loads stages all their keys in LDS; the per-bucket loop then runs on LDS only
+    uint64_t g0 = b_lo;
+    while (g0 < b_hi) {
+        int gmax = (int)((b_hi - g0 < 63) ? b_hi - g0 : 63);
+        const uint64_t oi = g0 + (uint64_t)lane;
+        const uint64_t offv = off[oi <= n_buckets ? oi : n_buckets];
+        const uint64_t gs = __shfl(offv, 0);
+        // largest prefix of buckets whose keys fit the staging buffer (lane l: does bucket l-1 end inside?)
+        const bool fits = lane >= 1 && lane <= gmax && (offv - gs) <= (uint64_t)STAGE_KEYS;
+        const uint64_t fm = __ballot(fits) >> 1; // bit j: buckets 0..j fit
+        int gcount = (fm == ~0ull >> 1) ? 63 : __builtin_ctzll(~fm);
+        if (gcount > gmax)
+            gcount = gmax;
+        const bool staged = gcount > 0;
+        if (!staged)
+            gcount = 1; // a single bucket larger than the staging buffer: streamed from global memory
+        const uint64_t ge = __shfl(offv, gcount);
+        const uint64_t base4 = gs & ~3ull; // 8-byte aligned start of the staged window
+        if (staged) {
+            const uint32_t nquads = (uint32_t)((ge - base4 + 3) / 4);
+            const uint2 *src = reinterpret_cast<const uint2 *>(keys + base4);
+            uint2 *dstq = reinterpret_cast<uint2 *>(stage);
+            for (uint32_t q = lane; q < nquads; q += 64)
+                dstq[q] = src[q];
+            asm volatile("" ::: "memory");
+        }
+        const uint32_t off_lo = (uint32_t)offv, off_hi = (uint32_t)(offv >> 32);
+        for (int j = 0; j < gcount; j++) {
+            // j is wave-uniform: v_readlane instead of a bpermute through the LDS pipe
+            const uint64_t s = ((uint64_t)__builtin_amdgcn_readlane(off_hi, j) << 32) | __builtin_amdgcn_readlane(off_lo, j);
+            const uint64_t e = ((uint64_t)__builtin_amdgcn_readlane(off_hi, j + 1) << 32) |
+                               __builtin_amdgcn_readlane(off_lo, j + 1);
+            const uint64_t n = e - s;
+            bool any_bit = false;
+            if (n == 0) {
+                // empty bucket: a slice of zeros
+            } else if (staged && n <= 64) {
+                const bool act = (uint64_t)lane < n;
+                const uint32_t key = act ? stage[(uint32_t)(s - base4) + lane] : 0u;
+                const uint32_t word = key & (CNT_WORDS - 1u), half = key >> (F_BITS - 1);
+                bool hot = false;
+                if (act) {
+                    // the lane that increments a counter last sees its final value minus one, so
+                    // "old + 1 > abundance" on every lane sets exactly the bits of the final counts
+                    const uint32_t old = (atomicAdd(&cnt[word], 1u << (16u * half)) >> (16u * half)) & 0xffffu;
+                    const uint32_t c = old + 1u;
+                    hot = (c > 255u ? 255u : c) > abundance; // pcon's u8 counters saturate at 255
+                    if (hot)
+                        atomicOr(&bmp[key >> 5], 1u << (key & 31u));
+                }
+                any_bit = __ballot(hot) != 0ull;
+                asm volatile("" ::: "memory");
+                if (act)
+                    cnt[word] = 0;
+            } else {
+                any_bit = true;
+                // large bucket: stream it, clamping between chunks so that the packed halves never carry
+                uint64_t done = 0;
+                while (done < n) {
+                    const uint64_t m = (n - done < CHUNK_MAX) ? n - done : CHUNK_MAX;
+                    for (uint64_t i = lane; i < m; i += 64) {
+                        const uint32_t kk = staged ? (uint32_t)stage[(uint32_t)(s - base4 + done + i)] : (uint32_t)keys[s + done + i];
+                        atomicAdd(&cnt[kk & (CNT_WORDS - 1u)], 1u << (16u * (kk >> (F_BITS - 1))));
+                    }
+                    asm volatile("" ::: "memory");
+                    done += m;
+                    if (done < n) {
+                        for (uint32_t w = lane; w < CNT_WORDS; w += 64) {
+                            const uint32_t v = cnt[w];
+                            const uint32_t a0 = v & 0xffffu, a1 = v >> 16;
+                            cnt[w] = (a0 > 255u ? 255u : a0) | ((a1 > 255u ? 255u : a1) << 16);
+                        }
+                        asm volatile("" ::: "memory");
+                    }
+                }
+                for (uint32_t w = lane; w < CNT_WORDS; w += 64) {
+                    const uint32_t v = cnt[w];
+                    if (v) {
+                        // word w holds hashes w (low half) and w + 2048 (high half)
+                        const uint32_t c0 = v & 0xffffu, c1 = v >> 16;
+                        if ((c0 > 255u ? 255u : c0) > abundance)
+                            atomicOr(&bmp[w >> 5], 1u << (w & 31u));
+                        if ((c1 > 255u ? 255u : c1) > abundance)
+                            atomicOr(&bmp[(w + CNT_WORDS) >> 5], 1u << (w & 31u));
+                        cnt[w] = 0;
+                    }
+                }
+            }
+            asm volatile("" ::: "memory");
+            // flush the slice: 128 words = 2 per lane (LDS is only touched when a bit was set)
+            uint32_t *dst = bits + (g0 + (uint64_t)j) * BIT_WORDS;
+            uint32_t w0 = 0, w1 = 0;
+            if (any_bit) {
+                w0 = bmp[2 * lane];
+                w1 = bmp[2 * lane + 1];
+                bmp[2 * lane] = 0;
+                bmp[2 * lane + 1] = 0;
+            }
+            *reinterpret_cast<uint2 *>(dst + 2 * lane) = make_uint2(w0, w1);
+            asm volatile("" ::: "memory");
+        }
+        g0 += (uint64_t)gcount;
+    }
+}
+
+// concatenates, per level-1 bucket, the segments of every batch (only needed for > 1 batch)
+__global__ __launch_bounds__(256) void merge_segments_kernel(const uint32_t *__restrict__ src,
+                                                             const uint64_t *__restrict__ src_off,
+                                                             const uint64_t *__restrict__ dst_off,
+                                                             const uint64_t *__restrict__ dst_shift, uint32_t B1,
+                                                             uint32_t *__restrict__ dst)
+{
+    for (uint32_t b = blockIdx.x; b < B1; b += gridDim.x) {
+        const uint64_t lo = src_off[b], hi = src_off[b + 1];
+        const uint64_t base = dst_off[b] + dst_shift[b];
+        for (uint64_t i = lo + threadIdx.x; i < hi; i += blockDim.x)
+            dst[base + (i - lo)] = src[i];
+    }
+}
+
+__global__ void add_counts_kernel(const uint64_t *__restrict__ off, uint32_t B1, uint32_t *__restrict__ counts,
+                                  uint64_t *__restrict__ shift_out)
+{
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B1) {
+        if (shift_out)
+            shift_out[b] = counts[b];
+        counts[b] += (uint32_t)(off[b + 1] - off[b]);
+    }
+}
+
+struct PartBatch {
+    uint32_t *d_keys = nullptr;  // keys after level 1, grouped by digit 1
+    uint64_t cap = 0, n = 0;
+    uint64_t *d_l1off = nullptr; // B1 + 1
+};
+
+} // namespace
+
+namespace brx {
+
+struct PartState {
+    Plan pl;
+    std::vector<PartBatch> batches, spare;
+    // generic workspace
+    uint32_t *d_ntiles = nullptr;   // per parent
+    uint64_t ntiles_cap = 0;
+    uint64_t *d_item_off = nullptr; // per parent + 1
+    uint64_t item_off_cap = 0;
+    uint32_t *d_item_parent = nullptr; // per work item
+    uint64_t item_parent_cap = 0;
+    uint64_t *d_scan_tmp = nullptr;
+    uint64_t scan_tmp_cap = 0;
+    unsigned long long *d_scalars = nullptr; // [0] n_items, [1] total keys of the last scan
+    uint32_t *d_hist[MAX_LEVELS] = {nullptr, nullptr, nullptr}; // child counts + cursors (2 x nchild)
+    uint64_t *d_coff[MAX_LEVELS] = {nullptr, nullptr, nullptr}; // child offsets (nchild + 1)
+    uint32_t *d_keys_mid = nullptr; // level-2 output when there are 3 levels
+    uint64_t keys_mid_cap = 0;
+    uint16_t *d_keys_fin = nullptr; // last level output
+    uint64_t keys_fin_cap = 0;
+    uint32_t *d_merged = nullptr;   // all batches merged per level-1 bucket (only when > 1 batch)
+    uint64_t merged_cap = 0;
+    uint64_t *d_l1off_all = nullptr;
+};
+
+static int ensure_dev(void **p, uint64_t *cap, uint64_t need_bytes)
+{
+    if (*p && need_bytes <= *cap)
+        return BRX_OK;
+    if (*p)
+        (void)hipFree(*p);
+    *p = nullptr;
+    *cap = 0;
+    const uint64_t want = need_bytes + need_bytes / 16 + 256;
+    hipError_t e = hipMalloc(p, want);
+    if (e != hipSuccess) {
+        set_error("hipMalloc(%llu B partition workspace): %s", (unsigned long long)want, hipGetErrorString(e));
+        return BRX_ERR_NOMEM;
+    }
+    *cap = want;
+    return BRX_OK;
+}
+
+bool part_supported(int k) { return 2 * k - 1 > F_BITS && 2 * k - 1 - F_BITS <= MAX_LEVELS * MAX_DIGIT_BITS; }
+
+int part_begin(brx_counter *c)
+{
+    PartState *st = new PartState();
+    c->part = st;
+    st->pl = make_plan(c->k);
+    const Plan &pl = st->pl;
+    hipError_t e = hipMalloc((void **)&st->d_scalars, 16);
+    for (int l = 0; l < pl.nlev && e == hipSuccess; l++) {
+        e = hipMalloc((void **)&st->d_hist[l], pl.nchild[l] * 2 * 4);
+        if (e == hipSuccess)
+            e = hipMalloc((void **)&st->d_coff[l], (pl.nchild[l] + 1) * 8);
+    }
+    if (e == hipSuccess)
+        e = hipMalloc((void **)&st->d_l1off_all, (pl.nchild[0] + 1) * 8);
+    if (e != hipSuccess) {
+        set_error("partition state alloc: %s", hipGetErrorString(e));
+        return BRX_ERR_NOMEM;
+    }
+    return BRX_OK;
+}
+
+void part_free(brx_counter *c)
+{
+    PartState *st = c->part;
+    if (!st)
+        return;
+    for (auto *v : {&st->batches, &st->spare})
+        for (auto &b : *v) {
+            if (b.d_keys)
+                (void)hipFree(b.d_keys);
+            if (b.d_l1off)
+                (void)hipFree(b.d_l1off);
+        }
+    for (void *p : {(void *)st->d_ntiles, (void *)st->d_item_off, (void *)st->d_item_parent, (void *)st->d_scan_tmp, (void *)st->d_scalars,
+                    (void *)st->d_hist[0], (void *)st->d_hist[1], (void *)st->d_hist[2], (void *)st->d_coff[0],
+                    (void *)st->d_coff[1], (void *)st->d_coff[2], (void *)st->d_keys_mid, (void *)st->d_keys_fin,
+                    (void *)st->d_merged, (void *)st->d_l1off_all})
+        if (p)
+            (void)hipFree(p);
+    delete st;
+    c->part = nullptr;
+}
+
+int part_reset(brx_counter *c)
+{
+    PartState *st = c->part;
+    for (auto &b : st->batches)
+        st->spare.push_back(b);
+    st->batches.clear();
+    return BRX_OK;
+}
+
+static int ensure_tables(PartState *st, uint64_t n_parents, uint64_t nchild, uint64_t max_items = 0)
+{
+    if (max_items) {
+        uint64_t capi = st->item_parent_cap;
+        BRX_TRY(ensure_dev((void **)&st->d_item_parent, &capi, (max_items + 1) * 4));
+        st->item_parent_cap = capi;
+    }
+    uint64_t capb = st->ntiles_cap;
+    BRX_TRY(ensure_dev((void **)&st->d_ntiles, &capb, (n_parents + 1) * 4));
+    st->ntiles_cap = capb;
+    capb = st->item_off_cap;
+    BRX_TRY(ensure_dev((void **)&st->d_item_off, &capb, (n_parents + 2) * 8));
+    st->item_off_cap = capb;
+    capb = st->scan_tmp_cap;
+    const uint64_t big = n_parents > nchild ? n_parents : nchild;
+    BRX_TRY(ensure_dev((void **)&st->d_scan_tmp, &capb, scan_tmp_bytes((uint32_t)big) + 64));
+    st->scan_tmp_cap = capb;
+    return BRX_OK;
+}
+
+static size_t scatter_lds_bytes(uint32_t tile, int bits)
+{
+    const size_t B = (size_t)1 << bits;
+    return (size_t)tile * 6 + B * 8 + B * 12 + 64;
+}
+
+// runs one level: work-item table -> histogram -> scan -> scatter
+template <typename OUT>
+static int run_level(PartState *st, int l, bool from_bases, LevelArgs a, uint64_t n_parents, uint64_t max_keys, void *keys_out,
+                     hipStream_t s, const char *tag_hist, const char *tag_scatter, uint64_t *coff_out)
+{
+    const Plan &pl = st->pl;
+    const uint64_t nchild = pl.nchild[l];
+    uint32_t *hist = st->d_hist[l], *cursor = st->d_hist[l] + nchild;
+    const uint32_t tile = (pl.bits[l] > 8) ? 8192u : 4096u;
+    BRX_TRY(ensure_tables(st, n_parents, nchild, max_keys / tile + n_parents + 1));
+    a.tile = tile;
+    a.rem_in = pl.rem_in[l];
+    a.bits = pl.bits[l];
+    a.hier = (l > 0) ? 1 : 0;
+    a.hist = hist;
+    a.coff = coff_out;
+    a.cursor = cursor;
+    a.keys_out = keys_out;
+    a.n_parents = n_parents;
+    a.item_off = st->d_item_off;
+    a.n_items = st->d_scalars;
+    if (from_bases)
+        tiles_from_reads_kernel<<<(unsigned)((n_parents + 255) / 256), 256, 0, s>>>(a.offsets, (uint32_t)n_parents, a.k, tile,
+                                                                                   st->d_ntiles);
+    else
+        tiles_from_offsets_kernel<<<(unsigned)((n_parents + 255) / 256), 256, 0, s>>>(a.poff, n_parents, tile, st->d_ntiles);
+    BRX_TRY(exclusive_scan_lens(st->d_ntiles, (uint32_t)n_parents, st->d_scan_tmp, st->d_item_off, st->d_scalars, s));
+    fill_item_parent_kernel<<<(unsigned)((n_parents + 255) / 256), 256, 0, s>>>(st->d_item_off, n_parents, st->d_item_parent);
+    a.item_parent = st->d_item_parent;
+    BRX_HIP(hipMemsetAsync(hist, 0, nchild * 2 * 4, s));
+    const int grid = 256 * 8;
+    const size_t B = (size_t)1 << a.bits;
+    {
+        KernelTimer t(tag_hist, s);
+        if (from_bases)
+            level_hist_kernel<true><<<grid, 256, B * 4, s>>>(a);
+        else
+            level_hist_kernel<false><<<grid, 256, B * 4, s>>>(a);
+    }
+    // child offsets; the scan's grand total lands in d_scalars[1]
+    BRX_TRY(exclusive_scan_lens(hist, (uint32_t)nchild, st->d_scan_tmp, coff_out, st->d_scalars + 1, s));
+    {
+        KernelTimer t(tag_scatter, s);
+        const size_t lds = scatter_lds_bytes(tile, a.bits);
+        if (from_bases)
+            level_scatter_kernel<true, OUT><<<grid, 256, lds, s>>>(a);
+        else
+            level_scatter_kernel<false, OUT><<<grid, 256, lds, s>>>(a);
+    }
+    BRX_HIP(hipGetLastError());
+    return BRX_OK;
+}
+
+int part_add_batch(brx_counter *c, const uint8_t *d_bases, const uint64_t *d_offsets, uint32_t n_reads,
+                   uint64_t total_bases, hipStream_t s)
+{
+    PartState *st = c->part;
+    const Plan &pl = st->pl;
+    const uint64_t max_keys = total_bases; // upper bound of the number of k-mers of this batch
+    PartBatch b;
+    for (size_t i = 0; i < st->spare.size(); i++)
+        if (st->spare[i].cap >= max_keys) {
+            b = st->spare[i];
+            st->spare.erase(st->spare.begin() + (long)i);
+            break;
+        }
+    if (!b.d_keys) {
+        uint64_t capb = 0;
+        BRX_TRY(ensure_dev((void **)&b.d_keys, &capb, (max_keys + 1) * 4));
+        b.cap = capb / 4;
+        BRX_HIP(hipMalloc((void **)&b.d_l1off, (pl.nchild[0] + 1) * 8));
+    }
+    LevelArgs a;
+    memset(&a, 0, sizeof(a));
+    a.bases = d_bases;
+    a.offsets = d_offsets;
+    a.k = pl.k;
+    BRX_TRY(run_level<uint32_t>(st, 0, true, a, n_reads, max_keys, b.d_keys, s, "part_l1_hist", "part_l1_scatter", b.d_l1off));
+    unsigned long long tot = 0;
+    BRX_HIP(hipMemcpyAsync(&tot, st->d_scalars + 1, 8, hipMemcpyDeviceToHost, s));
+    BRX_HIP(hipStreamSynchronize(s));
+    b.n = tot;
+    st->batches.push_back(b);
+    return BRX_OK;
+}
+
+int part_finish_into(brx_counter *c, uint32_t abundance, hipStream_t s, brx_set *dst)
+{
+    PartState *st = c->part;
+    const Plan &pl = st->pl;
+    const uint32_t B1 = (uint32_t)pl.nchild[0];
+    uint64_t total = 0;
+    for (auto &b : st->batches)
+        total += b.n;
+
+    const uint32_t *keys1 = nullptr;
+    const uint64_t *l1off = nullptr;
+    if (st->batches.empty()) {
+        BRX_HIP(hipMemsetAsync(dst->d_bits, 0, dst->nwords * 4, s));
+        return BRX_OK;
+    } else if (st->batches.size() == 1) {
+        keys1 = st->batches[0].d_keys;
+        l1off = st->batches[0].d_l1off;
+    } else {
+        uint64_t capb = st->merged_cap;
+        BRX_TRY(ensure_dev((void **)&st->d_merged, &capb, (total + 1) * 4));
+        st->merged_cap = capb;
+        BRX_TRY(ensure_tables(st, B1, B1));
+        uint32_t *cnts = st->d_hist[0];              // B1 running counts (the level-1 histogram is free again)
+        uint64_t *shift = (uint64_t *)st->d_coff[0]; // B1 u64 scratch
+        BRX_HIP(hipMemsetAsync(cnts, 0, (uint64_t)B1 * 4, s));
+        for (auto &b : st->batches)
+            add_counts_kernel<<<(B1 + 255) / 256, 256, 0, s>>>(b.d_l1off, B1, cnts, nullptr);
+        BRX_TRY(exclusive_scan_lens(cnts, B1, st->d_scan_tmp, st->d_l1off_all, st->d_scalars + 1, s));
+        BRX_HIP(hipMemsetAsync(cnts, 0, (uint64_t)B1 * 4, s));
+        for (auto &b : st->batches) {
+            add_counts_kernel<<<(B1 + 255) / 256, 256, 0, s>>>(b.d_l1off, B1, cnts, shift);
+            merge_segments_kernel<<<B1 < 4096u ? B1 : 4096u, 256, 0, s>>>(b.d_keys, b.d_l1off, st->d_l1off_all, shift, B1,
+                                                                         st->d_merged);
+        }
+        keys1 = st->d_merged;
+        l1off = st->d_l1off_all;
+    }
+
+    {
+        uint64_t capb = st->keys_fin_cap;
+        BRX_TRY(ensure_dev((void **)&st->d_keys_fin, &capb, (total + 64) * 2));
+        st->keys_fin_cap = capb;
+    }
+    LevelArgs a;
+    memset(&a, 0, sizeof(a));
+    a.k = pl.k;
+    const uint64_t *fin_off = nullptr;
+    if (pl.nlev == 2) {
+        a.keys_in = keys1;
+        a.poff = l1off;
+        BRX_TRY(run_level<uint16_t>(st, 1, false, a, pl.nchild[0], total, st->d_keys_fin, s, "part_l2_hist", "part_l2_scatter",
+                                    st->d_coff[1]));
+        fin_off = st->d_coff[1];
+    } else {
+        uint64_t capb = st->keys_mid_cap;
+        BRX_TRY(ensure_dev((void **)&st->d_keys_mid, &capb, (total + 64) * 4));
+        st->keys_mid_cap = capb;
+        a.keys_in = keys1;
+        a.poff = l1off;
+        BRX_TRY(run_level<uint32_t>(st, 1, false, a, pl.nchild[0], total, st->d_keys_mid, s, "part_l2_hist", "part_l2_scatter",
+                                    st->d_coff[1]));
+        a.keys_in = st->d_keys_mid;
+        a.poff = st->d_coff[1];
+        BRX_TRY(run_level<uint16_t>(st, 2, false, a, pl.nchild[1], total, st->d_keys_fin, s, "part_l3_hist", "part_l3_scatter",
+                                    st->d_coff[2]));
+        fin_off = st->d_coff[2];
+    }
+    {
+        KernelTimer t("part_final_count", s);
+        const uint64_t nb = pl.nchild[pl.nlev - 1];
+        const uint64_t want_waves = nb < (256ull * 16ull * 8ull) ? nb : (256ull * 16ull * 8ull);
+        const int grid = (int)((want_waves + P3_WAVES - 1) / P3_WAVES);
+        final_count_kernel<<<grid, 64 * P3_WAVES, 0, s>>>(st->d_keys_fin, fin_off, nb, abundance, dst->d_bits);
+    }
+    BRX_HIP(hipGetLastError());
+    return BRX_OK;
+}
+
+} // namespace brx

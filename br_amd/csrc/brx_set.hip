@@ -205,6 +205,13 @@ int grid_for(uint64_t items, int per_block, int cap = 256 * 8)
 } // namespace
 
 namespace brx {
+bool part_supported(int k);
+int part_begin(brx_counter *c);
+void part_free(brx_counter *c);
+int part_reset(brx_counter *c);
+int part_add_batch(brx_counter *c, const uint8_t *d_bases, const uint64_t *d_offsets, uint32_t n_reads,
+                   uint64_t total_bases, hipStream_t s);
+int part_finish_into(brx_counter *c, uint32_t abundance, hipStream_t s, brx_set *dst);
 // used by the correction chain and the host-pointer entry points
 int upload_batch(const uint8_t *bases, const uint64_t *offsets, uint32_t n_reads, uint8_t **d_bases, uint64_t *bases_cap,
                  uint64_t **d_off, uint64_t *off_cap, uint64_t *total, hipStream_t stream)
@@ -432,10 +439,14 @@ int brx_set_count_begin(uint8_t k, int device, int strategy, brx_counter_t **out
         return BRX_ERR_ARG;
     BRX_TRY(check_k(k, true));
     BRX_TRY(use_device(device));
-    if (strategy == BRX_COUNT_AUTO)
-        strategy = BRX_COUNT_DENSE;
-    if (strategy != BRX_COUNT_DENSE) {
-        set_error("count strategy %d not implemented", strategy);
+    if (strategy == BRX_COUNT_AUTO) // the table-free path as soon as the u8 table would not fit the caches
+        strategy = (part_supported(k) && k >= 15) ? BRX_COUNT_SORTED : BRX_COUNT_DENSE;
+    if (strategy != BRX_COUNT_DENSE && strategy != BRX_COUNT_SORTED) {
+        set_error("unknown count strategy %d", strategy);
+        return BRX_ERR_ARG;
+    }
+    if (strategy == BRX_COUNT_SORTED && !part_supported(k)) {
+        set_error("partitioned count strategy supports 7 <= k <= 19 (got %d)", (int)k);
         return BRX_ERR_UNSUPPORTED;
     }
     brx_counter *c = new brx_counter();
@@ -443,13 +454,27 @@ int brx_set_count_begin(uint8_t k, int device, int strategy, brx_counter_t **out
     c->device = device;
     c->strategy = strategy;
     c->d_counts = nullptr;
+    c->part = nullptr;
     c->d_keys = nullptr;
     c->n_keys = c->cap_keys = 0;
     c->stream = nullptr;
     c->count_bytes = set_nbits(k) < 32 ? 32 : set_nbits(k); // one u8 per canonical k-mer, >= one output word
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
-    if (e == hipSuccess)
-        e = hipMalloc((void **)&c->d_counts, c->count_bytes);
+    if (e != hipSuccess) {
+        set_error("stream create: %s", hipGetErrorString(e));
+        brx_counter_free(c);
+        return BRX_ERR_HIP;
+    }
+    if (strategy == BRX_COUNT_SORTED) {
+        int st = part_begin(c);
+        if (st != BRX_OK) {
+            brx_counter_free(c);
+            return st;
+        }
+        *out = c;
+        return BRX_OK;
+    }
+    e = hipMalloc((void **)&c->d_counts, c->count_bytes);
     if (e == hipSuccess) {
         KernelTimer t("count_zero", c->stream);
         e = hipMemsetAsync(c->d_counts, 0, c->count_bytes, c->stream);
@@ -476,6 +501,8 @@ int brx_set_count_add_batch_device(brx_counter_t *c, const uint8_t *d_bases, con
     if (!n_reads)
         return BRX_OK;
     hipStream_t s = (hipStream_t)stream;
+    if (c->strategy == BRX_COUNT_SORTED)
+        return part_add_batch(c, d_bases, d_offsets, n_reads, total_bases, s);
     {
         KernelTimer t("count_dense", s);
         kmer_scatter_kernel<0><<<grid_for(n_reads, 1, 1 << 20), 256, 0, s>>>(d_bases, d_offsets, n_reads, c->k,
@@ -519,6 +546,8 @@ int brx_counter_reset(brx_counter_t *c, void *stream)
         return BRX_ERR_ARG;
     BRX_TRY(use_device(c->device));
     hipStream_t s = (hipStream_t)stream;
+    if (c->strategy == BRX_COUNT_SORTED)
+        return part_reset(c);
     if (c->d_counts) {
         KernelTimer t("count_zero", s);
         BRX_HIP(hipMemsetAsync(c->d_counts, 0, c->count_bytes, s));
@@ -538,6 +567,8 @@ int brx_set_count_finish_into(brx_counter_t *c, uint8_t abundance, void *stream,
     }
     BRX_TRY(use_device(c->device));
     hipStream_t s = (hipStream_t)stream; // nullptr = the legacy default stream, like any HIP API
+    if (c->strategy == BRX_COUNT_SORTED)
+        return part_finish_into(c, abundance, s, dst);
     {
         KernelTimer t("threshold", s);
         threshold_kernel<<<grid_for(dst->nwords, 256, 256 * 16), 256, 0, s>>>((const uint4 *)c->d_counts, dst->nwords,
@@ -620,6 +651,8 @@ void brx_counter_free(brx_counter_t *c)
     if (!c)
         return;
     if (use_device(c->device) == BRX_OK) {
+        if (c->part)
+            part_free(c);
         if (c->d_counts)
             (void)hipFree(c->d_counts);
         if (c->d_keys)

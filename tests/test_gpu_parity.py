@@ -101,32 +101,52 @@ def test_set_and_found_alt_kmer(unit_vectors):
     assert not gs.get(br_amd.seq2bit(d["set_kmers"][0].encode()))
 
 
-def test_set_build_kat(raw_reads, solid_fixture_bytes):
+STRATEGIES = [_lib.COUNT_DENSE, _lib.COUNT_SORTED]
+
+
+@pytest.mark.parametrize("strategy", STRATEGIES)
+def test_set_build_kat(raw_reads, solid_fixture_bytes, strategy):
     """raw.fasta, k=11, count > 2  ==  tests/data/raw.k11.a2.solid, bit for bit."""
-    gs = br_amd.Pcon.from_count(raw_reads, 11, 2)
+    gs = br_amd.Pcon.from_count(raw_reads, 11, 2, strategy=strategy)
     assert gs.to_solid_bytes() == solid_fixture_bytes
     # batching must not matter (count_fasta(reader, 8192))
-    gs2 = br_amd.Pcon.from_count(raw_reads, 11, 2, batch=7)
+    gs2 = br_amd.Pcon.from_count(raw_reads, 11, 2, batch=7, strategy=strategy)
     assert gs2.to_solid_bytes() == solid_fixture_bytes
 
 
-@pytest.mark.parametrize("k,abundance", [(5, 0), (9, 1), (13, 3), (15, 2)])
-def test_set_build_vs_oracle(raw_reads, k, abundance):
+@pytest.mark.parametrize("strategy", STRATEGIES)
+@pytest.mark.parametrize("k,abundance", [(5, 0), (7, 1), (9, 1), (13, 3), (15, 2), (17, 0)])
+def test_set_build_vs_oracle(raw_reads, k, abundance, strategy):
+    if strategy == _lib.COUNT_SORTED and k < 7:
+        with pytest.raises(_lib.BrxError):
+            br_amd.Counter(k, 0, strategy)
+        return
     reads = raw_reads[:40] + [b"", b"ACG", b"N" * 40, b"acgtacgtacgtacgtacgtacgt"]
-    gs = br_amd.Pcon.from_count(reads, k, abundance)
+    gs = br_amd.Pcon.from_count(reads, k, abundance, strategy=strategy)
     ref = O.Solid.from_count(k, O.count_reads(k, reads), abundance)
     assert gs.to_solid_bytes() == ref.to_bytes()
 
 
-def test_counter_saturates_at_255():
-    k = 5
-    reads = [b"A" * (k + 299)] * 3 + [b"ACGTACGTAC"]      # AAAAA seen 900 times
+@pytest.mark.parametrize("strategy,k", [(_lib.COUNT_DENSE, 5), (_lib.COUNT_DENSE, 7), (_lib.COUNT_SORTED, 7)])
+def test_counter_saturates_at_255(strategy, k):
+    reads = [b"A" * (k + 299)] * 3 + [b"ACGTACGTAC"]      # AAAAA.. seen 900 times
     for a in (0, 200, 254):
-        gs = br_amd.Pcon.from_count(reads, k, a)
+        gs = br_amd.Pcon.from_count(reads, k, a, strategy=strategy)
         ref = O.Solid.from_count(k, O.count_reads(k, reads), a)
         assert gs.to_solid_bytes() == ref.to_bytes()
         assert gs.get(0)
-    assert not br_amd.Pcon.from_count(reads, k, 255).get(0)   # nothing exceeds 255
+    assert not br_amd.Pcon.from_count(reads, k, 255, strategy=strategy).get(0)   # nothing exceeds 255
+
+
+def test_partitioned_huge_bucket():
+    """> 65 000 occurrences of k-mers inside one fine bucket: the chunk-and-clamp path of the LDS
+    counters (u16 halves must never carry) against the saturating oracle."""
+    k = 9
+    reads = [b"A" * 2000] * 80 + [b"AAAAAAAAC" * 30] * 40 + [b"ACGTTGCAAGGCTTACCGATAGGCAT" * 20]
+    for a in (0, 3, 254):
+        gs = br_amd.Pcon.from_count(reads, k, a, strategy=_lib.COUNT_SORTED)
+        ref = O.Solid.from_count(k, O.count_reads(k, reads), a)
+        assert gs.to_solid_bytes() == ref.to_bytes()
 
 
 def test_presence_build_vs_oracle(raw_reads):
@@ -307,11 +327,18 @@ def test_synthetic_build_and_correct(k):
     tot = synth.reads_device(cfg, 0, dg.data_ptr(), 0, n_reads, db.data_ptr(), db.numel(), do.data_ptr())
     stream = torch.cuda.current_stream().cuda_stream
 
-    cnt = br_amd.Counter(k)
-    cnt.add_batch_device(db.data_ptr(), do.data_ptr(), n_reads, tot, stream)
-    gs = cnt.finish(3, stream)
     ref = O.Solid.from_count(k, O.count_reads(k, reads), 3)
-    assert gs.to_solid_bytes() == ref.to_bytes()
+    for strategy in STRATEGIES:
+        cnt = br_amd.Counter(k, 0, strategy)
+        cnt.add_batch_device(db.data_ptr(), do.data_ptr(), n_reads, tot, stream)
+        gs = cnt.finish(3, stream)
+        assert gs.to_solid_bytes() == ref.to_bytes()
+        # reset + recount into an existing set (the bench's steady state)
+        cnt.reset(stream)
+        cnt.add_batch_device(db.data_ptr(), do.data_ptr(), n_reads, tot, stream)
+        cnt.finish_into(3, gs, stream)
+        torch.cuda.synchronize()
+        assert gs.to_solid_bytes() == ref.to_bytes()
     assert gs.popcount() > 0
 
     chain = br_amd.Chain(gs, [("one", 5, 7)], two_side=False)
