@@ -73,19 +73,223 @@ Plan make_plan(int k)
     return p;
 }
 
-// ---- tile tables ------------------------------------------------------------------------------------
-// ntiles[p] = ceil(count_p / tile); counts come from read lengths (level 1) or bucket offsets
-__global__ void tiles_from_reads_kernel(const uint64_t *__restrict__ offsets, uint32_t n_reads, int k, uint32_t tile,
-                                        uint32_t *__restrict__ ntiles)
+// ---- 2-bit packing of a window of bases into LDS -------------------------------------------------------
+// word w holds window-local bases 16w..16w+15, first base in the top bits, so a k-mer is a 2k-bit
+// field of the big-endian bit string.  pack4: ASCII bytes b0..b3 (b0 at the lowest address) ->
+// (c0<<6 | c1<<4 | c2<<2 | c3), c = (b >> 1) & 3.
+__device__ __forceinline__ uint32_t pack4(uint32_t w)
 {
-    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n_reads)
-        return;
-    const uint64_t len = offsets[r + 1] - offsets[r];
-    const uint64_t nk = len >= (uint64_t)k ? len - (uint64_t)k + 1 : 0;
-    ntiles[r] = (uint32_t)((nk + tile - 1) / tile);
+    uint32_t x = __builtin_bswap32((w >> 1) & 0x03030303u);
+    x |= x >> 6;
+    return (x | (x >> 12)) & 0xffu;
 }
 
+constexpr uint32_t L1_TILE = 8192;                    // k-mer start positions per level-1 work item
+constexpr uint32_t PACK_WORDS = L1_TILE / 16 + 4;     // bases of the tile + k - 1 + slack, 16 per word
+constexpr uint32_t BND_WORDS = (L1_TILE + 64) / 32 + 2; // read-boundary bitmap of the same window
+
+// packs bases [g0, g0 + nbases) of the batch into pk[]; bases beyond `total` read as A
+__device__ __forceinline__ void pack_window(const uint8_t *__restrict__ bases, uint64_t total, uint64_t g0, uint32_t nbases,
+                                            uint32_t *__restrict__ pk)
+{
+    const uint32_t nwords = (nbases + 15u) / 16u;
+    for (uint32_t w = threadIdx.x; w < nwords; w += 256) {
+        const uint64_t p = g0 + 16ull * w;
+        uint32_t v[4] = {0, 0, 0, 0};
+        if (p + 16 <= total) {
+            uint4 q;
+            __builtin_memcpy(&q, bases + p, 16); // one (possibly unaligned) global_load_dwordx4
+            v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+        } else {
+            for (uint32_t j = 0; j < 16; j++)
+                if (p + j < total)
+                    v[j >> 2] |= (uint32_t)bases[p + j] << (8u * (j & 3u));
+        }
+        pk[w] = (pack4(v[0]) << 24) | (pack4(v[1]) << 16) | (pack4(v[2]) << 8) | pack4(v[3]);
+    }
+}
+
+// forward k-mer starting at window-local base `pos`
+__device__ __forceinline__ uint64_t kmer_at(const uint32_t *__restrict__ pk, uint32_t pos, int k)
+{
+    const uint32_t w = pos >> 4, sh = 2u * (pos & 15u);
+    const uint64_t hi = ((uint64_t)pk[w] << 32) | pk[w + 1];
+    const uint64_t lo = pk[w + 2];
+    const uint64_t val = sh ? ((hi << sh) | (lo >> (32u - sh))) : hi;
+    return val >> (64 - 2 * k);
+}
+
+// ---- level 1: tiles of the flat base stream ---------------------------------------------------------------
+// Work item i = k-mer start positions [i*L1_TILE, (i+1)*L1_TILE) of the concatenated batch.  A k-mer is
+// valid iff it does not run over a read boundary: bnd[] has a bit for every read START (and for the
+// end of the batch) inside the window; position p is valid iff no bit is set in (p, p+k-1].
+struct L1Args {
+    const uint8_t *bases;
+    const uint64_t *offsets; // n_reads + 1 (absolute indices into bases; the flat stream starts at offsets[0])
+    uint32_t n_reads;
+    uint64_t total;          // bases in the batch
+    uint32_t n_items;
+    int k, nbits, bits;      // digit = hash >> (nbits - bits)
+    uint32_t *matrix;        // [B][n_items] per-tile digit counts (hist) ...
+    const uint64_t *pos;     // ... and their exclusive scan (scatter)
+    uint32_t *keys_out;      // hash with the digit stripped
+};
+
+__device__ __forceinline__ void l1_prepare(const L1Args &a, uint32_t item, uint32_t *pk, uint32_t *bnd, uint32_t *sh_r0,
+                                           uint32_t &n_here)
+{
+    const uint64_t off0 = a.offsets[0];
+    const uint64_t g0 = (uint64_t)item * L1_TILE;
+    const uint64_t left = a.total - g0;
+    n_here = (uint32_t)(left < L1_TILE ? left : L1_TILE);
+    const uint32_t win = n_here + (uint32_t)a.k + 32u; // bases needed (+ slack for the 3-word extract)
+    pack_window(a.bases + off0, a.total, g0, win, pk);
+    for (uint32_t w = threadIdx.x; w < BND_WORDS; w += 256)
+        bnd[w] = 0;
+    if (threadIdx.x == 0) {
+        // first read that starts after g0: upper_bound(offsets, g0)
+        uint32_t lo = 0, hi = a.n_reads + 1;
+        while (lo < hi) {
+            const uint32_t mid = lo + (hi - lo) / 2;
+            if (a.offsets[mid] - off0 <= g0)
+                lo = mid + 1;
+            else
+                hi = mid;
+        }
+        *sh_r0 = lo;
+    }
+    __syncthreads();
+    const uint64_t lim = g0 + n_here + (uint64_t)a.k; // boundaries at window-local positions <= n_here + k - 1 matter
+    for (uint32_t r = *sh_r0 + threadIdx.x; r <= a.n_reads; r += 256) {
+        const uint64_t o = a.offsets[r] - off0; // offsets[n_reads] - off0 == total: the batch end is a boundary too
+        if (o >= lim)
+            break;
+        const uint32_t p = (uint32_t)(o - g0);
+        atomicOr(&bnd[p >> 5], 1u << (p & 31u));
+    }
+    __syncthreads();
+}
+
+// true iff no read boundary lies in window-local positions (p, p + k - 1]
+__device__ __forceinline__ bool l1_valid(const uint32_t *bnd, uint32_t p, int k)
+{
+    const uint32_t q = p + 1u; // first position to test, k-1 <= 30 bits
+    const uint32_t w = q >> 5, sh = q & 31u;
+    const uint64_t two = ((uint64_t)bnd[w + 1] << 32) | bnd[w];
+    const uint32_t bits = (uint32_t)(two >> sh) & ((k > 1) ? ((1u << (k - 1)) - 1u) : 0u);
+    return bits == 0u;
+}
+
+__global__ __launch_bounds__(256) void l1_hist_kernel(L1Args a)
+{
+    extern __shared__ uint32_t lds[]; // hist[B]
+    __shared__ uint32_t pk[PACK_WORDS];
+    __shared__ uint32_t bnd[BND_WORDS];
+    __shared__ uint32_t sh_r0;
+    const uint32_t B = 1u << a.bits;
+    const int shift = a.nbits - a.bits;
+    for (uint32_t item = blockIdx.x; item < a.n_items; item += gridDim.x) {
+        for (uint32_t b = threadIdx.x; b < B; b += 256)
+            lds[b] = 0;
+        uint32_t n_here;
+        l1_prepare(a, item, pk, bnd, &sh_r0, n_here);
+        for (uint32_t p = threadIdx.x; p < n_here; p += 256)
+            if (l1_valid(bnd, p, a.k))
+                atomicAdd(&lds[(uint32_t)(khash(kmer_at(pk, p, a.k), a.k) >> shift)], 1u);
+        __syncthreads();
+        for (uint32_t b = threadIdx.x; b < B; b += 256)
+            a.matrix[(uint64_t)b * a.n_items + item] = lds[b];
+        __syncthreads();
+    }
+}
+
+// shared tail of the scatter kernels: block scan of cntv -> lofs/lcur, returns nothing (all in LDS)
+__device__ __forceinline__ void block_scan_bins(uint32_t B, const uint32_t *cntv, uint32_t *lofs, uint32_t *lcur, uint32_t *sh_wsum)
+{
+    const uint32_t BPT = (B + 255u) / 256u; // bins per thread (1 or 2)
+    uint32_t mine = 0;
+    for (uint32_t q = 0; q < BPT; q++) {
+        const uint32_t b = threadIdx.x * BPT + q;
+        if (b < B)
+            mine += cntv[b];
+    }
+    uint32_t incl = mine;
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t t = __shfl_up(incl, d);
+        if ((threadIdx.x & 63) >= (unsigned)d)
+            incl += t;
+    }
+    if ((threadIdx.x & 63) == 63)
+        sh_wsum[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    uint32_t wbase = 0;
+    for (uint32_t w = 0; w < (threadIdx.x >> 6); w++)
+        wbase += sh_wsum[w];
+    uint32_t run = wbase + incl - mine;
+    for (uint32_t q = 0; q < BPT; q++) {
+        const uint32_t b = threadIdx.x * BPT + q;
+        if (b < B) {
+            lofs[b] = run;
+            lcur[b] = run;
+            run += cntv[b];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void l1_scatter_kernel(L1Args a)
+{
+    // LDS: stage_key[T] (u32) | stage_dig[T] (u16) | gbase[B] (u64) | cnt[B] | lofs[B] | lcur[B]
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+    __shared__ uint32_t pk[PACK_WORDS];
+    __shared__ uint32_t bnd[BND_WORDS];
+    __shared__ uint32_t sh_r0;
+    __shared__ uint32_t sh_wsum[4];
+    const uint32_t T = L1_TILE;
+    const uint32_t B = 1u << a.bits;
+    uint32_t *stage_key = (uint32_t *)lds_raw;
+    uint16_t *stage_dig = (uint16_t *)(lds_raw + (size_t)T * 4);
+    unsigned long long *gbase = (unsigned long long *)(lds_raw + (size_t)T * 6);
+    uint32_t *cntv = (uint32_t *)(lds_raw + (size_t)T * 6 + (size_t)B * 8);
+    uint32_t *lofs = cntv + B;
+    uint32_t *lcur = lofs + B;
+    const int shift = a.nbits - a.bits;
+    const uint64_t child_mask = (1ull << shift) - 1ull;
+    for (uint32_t item = blockIdx.x; item < a.n_items; item += gridDim.x) {
+        for (uint32_t b = threadIdx.x; b < B; b += 256) {
+            cntv[b] = a.matrix[(uint64_t)b * a.n_items + item]; // the histogram pass already counted this tile
+            gbase[b] = a.pos[(uint64_t)b * a.n_items + item];
+        }
+        uint32_t n_here;
+        l1_prepare(a, item, pk, bnd, &sh_r0, n_here);
+        block_scan_bins(B, cntv, lofs, lcur, sh_wsum);
+        __syncthreads();
+        for (uint32_t p = threadIdx.x; p < n_here; p += 256)
+            if (l1_valid(bnd, p, a.k)) {
+                const uint64_t h = khash(kmer_at(pk, p, a.k), a.k);
+                const uint32_t d = (uint32_t)(h >> shift);
+                const uint32_t slot = atomicAdd(&lcur[d], 1u);
+                stage_key[slot] = (uint32_t)(h & child_mask);
+                stage_dig[slot] = (uint16_t)d;
+            }
+        __syncthreads();
+        const uint32_t n_tile = lofs[B - 1] + cntv[B - 1];
+        for (uint32_t idx = threadIdx.x; idx < n_tile; idx += 256) {
+            const uint32_t d = stage_dig[idx];
+            a.keys_out[gbase[d] + (idx - lofs[d])] = stage_key[idx];
+        }
+        __syncthreads();
+    }
+}
+
+// child offsets of level 1: coff[b] = pos[b * n_items], coff[B] = total
+__global__ void l1_coff_kernel(const uint64_t *__restrict__ pos, uint32_t B, uint32_t n_items, uint64_t *__restrict__ coff)
+{
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b <= B)
+        coff[b] = pos[(uint64_t)b * n_items];
+}
+
+// ---- levels >= 2: tiles inside parent buckets -----------------------------------------------------------------
 __global__ void tiles_from_offsets_kernel(const uint64_t *__restrict__ poff, uint64_t n_parents, uint32_t tile,
                                           uint32_t *__restrict__ ntiles)
 {
@@ -96,222 +300,7 @@ __global__ void tiles_from_offsets_kernel(const uint64_t *__restrict__ poff, uin
     ntiles[p] = (uint32_t)((n + tile - 1) / tile);
 }
 
-// ---- one radix level ----------------------------------------------------------------------------------
-struct LevelArgs {
-    // source: bases (level 1) or u32 keys of the previous level
-    const uint8_t *bases;
-    const uint64_t *offsets;   // read offsets (level 1)
-    const uint32_t *keys_in;
-    const uint64_t *poff;      // parent bucket offsets into keys_in (levels >= 2)
-    uint64_t n_parents;
-    const uint64_t *item_off;  // n_parents + 1: first work item of each parent
-    const uint32_t *item_parent; // per work item: its parent
-    const unsigned long long *n_items; // device scalar = item_off[n_parents]
-    uint32_t tile;             // keys per work item
-    int k;
-    int rem_in, bits;          // digit = (key >> (rem_in - bits))
-    int hier;                  // 1: child bucket = parent * B + digit; 0 (level 1): child = digit
-    uint32_t *hist;            // child counts
-    const uint64_t *coff;      // child offsets (scatter)
-    uint32_t *cursor;          // child fill cursors (scatter)
-    void *keys_out;
-};
-
-// ---- level-1 source: the tile's bases, packed 2 bits each into LDS ----------------------------------
-// word w holds tile-local bases 16w..16w+15, first base in the top bits, so a k-mer is a 2k-bit
-// field of the big-endian bit string.  pack4: ASCII bytes b0..b3 (b0 at the lowest address) ->
-// (c0<<6 | c1<<4 | c2<<2 | c3), c = (b >> 1) & 3.
-__device__ __forceinline__ uint32_t pack4(uint32_t w)
-{
-    uint32_t x = __builtin_bswap32((w >> 1) & 0x03030303u);
-    x |= x >> 6;
-    return (x | (x >> 12)) & 0xffu;
-}
-
-constexpr uint32_t PACK_WORDS_MAX = 8192 / 16 + 4;
-
-// packs bases [b0, b0 + nbases) of `seq` (read length len) into pk[]; out-of-read bases read as A
-__device__ __forceinline__ void pack_tile_bases(const uint8_t *__restrict__ seq, uint64_t len, uint64_t b0, uint32_t nbases,
-                                                uint32_t *__restrict__ pk)
-{
-    const uint32_t nwords = (nbases + 15u) / 16u;
-    for (uint32_t w = threadIdx.x; w < nwords; w += 256) {
-        const uint64_t p = b0 + 16ull * w;
-        uint32_t v[4] = {0, 0, 0, 0};
-        if (p + 16 <= len) {
-            uint4 q;
-            __builtin_memcpy(&q, seq + p, 16); // one (possibly unaligned) global_load_dwordx4
-            v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
-        } else {
-            for (uint32_t j = 0; j < 16; j++)
-                if (p + j < len)
-                    v[j >> 2] |= (uint32_t)seq[p + j] << (8u * (j & 3u));
-        }
-        pk[w] = (pack4(v[0]) << 24) | (pack4(v[1]) << 16) | (pack4(v[2]) << 8) | pack4(v[3]);
-    }
-}
-
-// forward k-mer starting at tile-local base `pos`
-__device__ __forceinline__ uint64_t kmer_at(const uint32_t *__restrict__ pk, uint32_t pos, int k)
-{
-    const uint32_t w = pos >> 4, sh = 2u * (pos & 15u);
-    const uint64_t hi = ((uint64_t)pk[w] << 32) | pk[w + 1];
-    const uint64_t lo = pk[w + 2];
-    const uint64_t val = sh ? ((hi << sh) | (lo >> (32u - sh))) : hi;
-    return val >> (64 - 2 * k);
-}
-
-// Visits the keys of one tile: thread t gets the tile-local positions t, t+256, ... (consecutive
-// lanes, consecutive keys).  For level 1 the bases must already be packed in pk[] (prepare_tile).
-template <bool FROM_BASES>
-__device__ __forceinline__ uint32_t prepare_tile(const LevelArgs &a, uint64_t parent, uint64_t tile_in_parent, uint32_t *pk,
-                                                 uint64_t &key_base)
-{
-    if (FROM_BASES) {
-        const uint64_t s = a.offsets[parent];
-        const uint64_t len = a.offsets[parent + 1] - s;
-        const uint64_t nk = len - (uint64_t)a.k + 1; // a parent with tiles has len >= k
-        const uint64_t p0 = tile_in_parent * a.tile;
-        const uint32_t n_here = (uint32_t)((nk - p0 < a.tile) ? nk - p0 : a.tile);
-        pack_tile_bases(a.bases + s, len, p0, n_here + (uint32_t)a.k - 1u + 32u, pk);
-        key_base = 0;
-        return n_here;
-    } else {
-        const uint64_t lo = a.poff[parent] + tile_in_parent * a.tile;
-        const uint64_t hi_p = a.poff[parent + 1];
-        key_base = lo;
-        return (uint32_t)((hi_p - lo < a.tile) ? hi_p - lo : a.tile);
-    }
-}
-
-template <bool FROM_BASES>
-__device__ __forceinline__ uint64_t tile_key(const LevelArgs &a, const uint32_t *pk, uint64_t key_base, uint32_t pos)
-{
-    if (FROM_BASES)
-        return khash(kmer_at(pk, pos, a.k), a.k);
-    return a.keys_in[key_base + pos];
-}
-
-template <bool FROM_BASES>
-__global__ __launch_bounds__(256) void level_hist_kernel(LevelArgs a)
-{
-    extern __shared__ uint32_t lds[]; // hist[B]
-    __shared__ uint32_t pk[FROM_BASES ? PACK_WORDS_MAX : 1];
-    const uint32_t B = 1u << a.bits;
-    const int shift = a.rem_in - a.bits;
-    const unsigned long long n_items = *a.n_items;
-    for (unsigned long long item = blockIdx.x; item < n_items; item += gridDim.x) {
-        const uint64_t parent = a.item_parent[item];
-        for (uint32_t b = threadIdx.x; b < B; b += 256)
-            lds[b] = 0;
-        uint64_t key_base;
-        const uint32_t n_here = prepare_tile<FROM_BASES>(a, parent, item - a.item_off[parent], pk, key_base);
-        __syncthreads();
-        for (uint32_t pos = threadIdx.x; pos < n_here; pos += 256) {
-            const uint64_t key = tile_key<FROM_BASES>(a, pk, key_base, pos);
-            atomicAdd(&lds[(uint32_t)(key >> shift) & (B - 1u)], 1u);
-        }
-        __syncthreads();
-        const uint64_t cbase = a.hier ? parent * B : 0;
-        for (uint32_t b = threadIdx.x; b < B; b += 256) {
-            const uint32_t c = lds[b];
-            if (c)
-                atomicAdd(&a.hist[cbase + b], c);
-        }
-        __syncthreads();
-    }
-}
-
-template <bool FROM_BASES, typename OUT>
-__global__ __launch_bounds__(256) void level_scatter_kernel(LevelArgs a)
-{
-    // LDS: stage_key[T] (u32) | stage_dig[T] (u16) | gbase[B] (u64) | cnt[B] | lofs[B] | lcur[B]
-    extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
-    __shared__ uint32_t sh_wsum[4];
-    __shared__ uint32_t pk[FROM_BASES ? PACK_WORDS_MAX : 1];
-    const uint32_t T = a.tile;
-    const uint32_t B = 1u << a.bits;
-    uint32_t *stage_key = (uint32_t *)lds_raw;
-    uint16_t *stage_dig = (uint16_t *)(lds_raw + (size_t)T * 4);
-    unsigned long long *gbase = (unsigned long long *)(lds_raw + (size_t)T * 6);
-    uint32_t *cntv = (uint32_t *)(lds_raw + (size_t)T * 6 + (size_t)B * 8);
-    uint32_t *lofs = cntv + B;
-    uint32_t *lcur = lofs + B;
-    const int shift = a.rem_in - a.bits;
-    const uint32_t child_mask = (shift >= 32) ? 0xffffffffu : ((1u << shift) - 1u);
-    OUT *out = (OUT *)a.keys_out;
-    const unsigned long long n_items = *a.n_items;
-    const uint32_t BPT = (B + 255u) / 256u; // bins per thread in the block scan (1 or 2)
-
-    for (unsigned long long item = blockIdx.x; item < n_items; item += gridDim.x) {
-        const uint64_t parent = a.item_parent[item];
-        for (uint32_t b = threadIdx.x; b < B; b += 256)
-            cntv[b] = 0;
-        uint64_t key_base;
-        const uint32_t n_here = prepare_tile<FROM_BASES>(a, parent, item - a.item_off[parent], pk, key_base);
-        __syncthreads();
-        // sweep 1: digits -> LDS histogram; the digit (and the stripped key) is parked in the staging
-        // buffer at the key's own position so that sweep 2 does not have to re-derive it
-        for (uint32_t pos = threadIdx.x; pos < n_here; pos += 256) {
-            const uint64_t key = tile_key<FROM_BASES>(a, pk, key_base, pos);
-            const uint32_t d = (uint32_t)(key >> shift) & (B - 1u);
-            atomicAdd(&cntv[d], 1u);
-        }
-        __syncthreads();
-        // block exclusive scan of cntv[0..B) -> lofs; thread t owns bins [t*BPT, t*BPT+BPT)
-        {
-            uint32_t mine = 0;
-            for (uint32_t q = 0; q < BPT; q++) {
-                const uint32_t b = threadIdx.x * BPT + q;
-                if (b < B)
-                    mine += cntv[b];
-            }
-            uint32_t incl = mine;
-            for (int d = 1; d < 64; d <<= 1) {
-                const uint32_t t = __shfl_up(incl, d);
-                if ((threadIdx.x & 63) >= (unsigned)d)
-                    incl += t;
-            }
-            if ((threadIdx.x & 63) == 63)
-                sh_wsum[threadIdx.x >> 6] = incl;
-            __syncthreads();
-            uint32_t wbase = 0;
-            for (uint32_t w = 0; w < (threadIdx.x >> 6); w++)
-                wbase += sh_wsum[w];
-            uint32_t run = wbase + incl - mine;
-            const uint64_t cbase = a.hier ? parent * B : 0;
-            for (uint32_t q = 0; q < BPT; q++) {
-                const uint32_t b = threadIdx.x * BPT + q;
-                if (b < B) {
-                    const uint32_t c = cntv[b];
-                    lofs[b] = run;
-                    lcur[b] = run;
-                    // reserve the run inside child bucket (cbase + b)
-                    gbase[b] = c ? a.coff[cbase + b] + atomicAdd(&a.cursor[cbase + b], c) : 0ull;
-                    run += c;
-                }
-            }
-        }
-        __syncthreads();
-        // sweep 2: rank every key inside its bucket, park it in the staging buffer
-        for (uint32_t pos = threadIdx.x; pos < n_here; pos += 256) {
-            const uint64_t key = tile_key<FROM_BASES>(a, pk, key_base, pos);
-            const uint32_t d = (uint32_t)(key >> shift) & (B - 1u);
-            const uint32_t slot = atomicAdd(&lcur[d], 1u);
-            stage_key[slot] = (uint32_t)key & child_mask;
-            stage_dig[slot] = (uint16_t)d;
-        }
-        __syncthreads();
-        // write-out: consecutive lanes, consecutive addresses inside each bucket's run
-        for (uint32_t idx = threadIdx.x; idx < n_here; idx += 256) {
-            const uint32_t d = stage_dig[idx];
-            out[gbase[d] + (idx - lofs[d])] = (OUT)stage_key[idx];
-        }
-        __syncthreads();
-    }
-}
-
-// item -> parent map (replaces a binary search per work item)
+// item -> parent map (instead of a binary search per work item)
 __global__ void fill_item_parent_kernel(const uint64_t *__restrict__ item_off, uint64_t n_parents,
                                         uint32_t *__restrict__ item_parent)
 {
@@ -321,6 +310,131 @@ __global__ void fill_item_parent_kernel(const uint64_t *__restrict__ item_off, u
     const uint64_t lo = item_off[p], hi = item_off[p + 1];
     for (uint64_t i = lo; i < hi; i++)
         item_parent[i] = (uint32_t)p;
+}
+
+struct LnArgs {
+    const uint32_t *keys_in;
+    const uint64_t *poff;        // parent bucket offsets into keys_in
+    uint64_t n_parents;
+    const uint64_t *item_off;    // n_parents + 1: first work item of each parent
+    const uint32_t *item_parent; // per work item
+    const unsigned long long *n_items; // device scalar
+    uint32_t tile;
+    int rem_in, bits;            // digit = key >> (rem_in - bits)
+    uint32_t *matrix;            // [parent][B][tiles of the parent] digit counts, index B*item_off[p] + b*ntiles_p + t
+    const uint64_t *pos;         // exclusive scan of matrix
+    void *keys_out;
+};
+
+template <int KPT>
+__device__ __forceinline__ uint32_t ln_load(const LnArgs &a, uint64_t parent, uint64_t t, uint32_t (&key)[KPT])
+{
+    const uint64_t lo = a.poff[parent] + t * a.tile;
+    const uint64_t hi_p = a.poff[parent + 1];
+    const uint64_t hi = (lo + a.tile < hi_p) ? lo + a.tile : hi_p;
+    uint32_t cnt = 0;
+#pragma unroll
+    for (int q = 0; q < KPT; q++) {
+        const uint64_t i = lo + (uint64_t)q * 256 + threadIdx.x;
+        if (i < hi) {
+            key[q] = a.keys_in[i];
+            cnt = q + 1;
+        }
+    }
+    return cnt;
+}
+
+template <int KPT>
+__global__ __launch_bounds__(256) void ln_hist_kernel(LnArgs a)
+{
+    extern __shared__ uint32_t lds[]; // hist[B]
+    const uint32_t B = 1u << a.bits;
+    const int shift = a.rem_in - a.bits;
+    const unsigned long long n_items = *a.n_items;
+    for (unsigned long long item = blockIdx.x; item < n_items; item += gridDim.x) {
+        const uint64_t parent = a.item_parent[item];
+        const uint64_t io = a.item_off[parent];
+        const uint64_t t = item - io, nt = a.item_off[parent + 1] - io;
+        for (uint32_t b = threadIdx.x; b < B; b += 256)
+            lds[b] = 0;
+        __syncthreads();
+        uint32_t key[KPT];
+        const uint32_t cnt = ln_load<KPT>(a, parent, t, key);
+#pragma unroll
+        for (int q = 0; q < KPT; q++)
+            if ((uint32_t)q < cnt)
+                atomicAdd(&lds[(key[q] >> shift) & (B - 1u)], 1u);
+        __syncthreads();
+        for (uint32_t b = threadIdx.x; b < B; b += 256)
+            a.matrix[B * io + (uint64_t)b * nt + t] = lds[b];
+        __syncthreads();
+    }
+}
+
+template <int KPT, typename OUT>
+__global__ __launch_bounds__(256) void ln_scatter_kernel(LnArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+    __shared__ uint32_t sh_wsum[4];
+    const uint32_t T = a.tile;
+    const uint32_t B = 1u << a.bits;
+    uint32_t *stage_key = (uint32_t *)lds_raw;
+    uint16_t *stage_dig = (uint16_t *)(lds_raw + (size_t)T * 4);
+    unsigned long long *gbase = (unsigned long long *)(lds_raw + (size_t)T * 6);
+    uint32_t *cntv = (uint32_t *)(lds_raw + (size_t)T * 6 + (size_t)B * 8);
+    uint32_t *lofs = cntv + B;
+    uint32_t *lcur = lofs + B;
+    const int shift = a.rem_in - a.bits;
+    const uint32_t child_mask = (1u << shift) - 1u;
+    OUT *out = (OUT *)a.keys_out;
+    const unsigned long long n_items = *a.n_items;
+    for (unsigned long long item = blockIdx.x; item < n_items; item += gridDim.x) {
+        const uint64_t parent = a.item_parent[item];
+        const uint64_t io = a.item_off[parent];
+        const uint64_t t = item - io, nt = a.item_off[parent + 1] - io;
+        for (uint32_t b = threadIdx.x; b < B; b += 256) {
+            const uint64_t mi = B * io + (uint64_t)b * nt + t;
+            cntv[b] = a.matrix[mi];
+            gbase[b] = a.pos[mi];
+        }
+        uint32_t key[KPT];
+        const uint32_t cnt = ln_load<KPT>(a, parent, t, key);
+        __syncthreads();
+        block_scan_bins(B, cntv, lofs, lcur, sh_wsum);
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < KPT; q++)
+            if ((uint32_t)q < cnt) {
+                const uint32_t d = (key[q] >> shift) & (B - 1u);
+                const uint32_t slot = atomicAdd(&lcur[d], 1u);
+                stage_key[slot] = key[q] & child_mask;
+                stage_dig[slot] = (uint16_t)d;
+            }
+        __syncthreads();
+        const uint32_t n_tile = lofs[B - 1] + cntv[B - 1];
+        for (uint32_t idx = threadIdx.x; idx < n_tile; idx += 256) {
+            const uint32_t d = stage_dig[idx];
+            out[gbase[d] + (idx - lofs[d])] = (OUT)stage_key[idx];
+        }
+        __syncthreads();
+    }
+}
+
+// child offsets of a level >= 2: coff[p*B + b] = pos[B*item_off[p] + b*ntiles_p] (empty parents: the
+// position where the next non-empty parent starts), coff[n_parents*B] = total
+__global__ void ln_coff_kernel(const uint64_t *__restrict__ pos, const uint64_t *__restrict__ item_off, uint64_t n_parents,
+                               uint32_t B, uint64_t *__restrict__ coff)
+{
+    const uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c > n_parents * B)
+        return;
+    if (c == n_parents * B) {
+        coff[c] = pos[(uint64_t)B * item_off[n_parents]];
+        return;
+    }
+    const uint64_t p = c / B, b = c % B;
+    const uint64_t io = item_off[p], nt = item_off[p + 1] - io;
+    coff[c] = pos[(uint64_t)B * io + b * nt];
 }
 
 // ---- final stage: one wavefront per fine bucket (4096 hashes) -----------------------------------------
@@ -502,24 +616,29 @@ struct PartState {
     Plan pl;
     std::vector<PartBatch> batches, spare;
     // generic workspace
-    uint32_t *d_ntiles = nullptr;   // per parent
+    uint32_t *d_ntiles = nullptr;      // per parent
     uint64_t ntiles_cap = 0;
-    uint64_t *d_item_off = nullptr; // per parent + 1
+    uint64_t *d_item_off = nullptr;    // per parent + 1
     uint64_t item_off_cap = 0;
     uint32_t *d_item_parent = nullptr; // per work item
     uint64_t item_parent_cap = 0;
+    uint32_t *d_matrix = nullptr;      // per-tile digit counts
+    uint64_t matrix_cap = 0;
+    uint64_t *d_pos = nullptr;         // exclusive scan of the matrix
+    uint64_t pos_cap = 0;
     uint64_t *d_scan_tmp = nullptr;
     uint64_t scan_tmp_cap = 0;
     unsigned long long *d_scalars = nullptr; // [0] n_items, [1] total keys of the last scan
-    uint32_t *d_hist[MAX_LEVELS] = {nullptr, nullptr, nullptr}; // child counts + cursors (2 x nchild)
     uint64_t *d_coff[MAX_LEVELS] = {nullptr, nullptr, nullptr}; // child offsets (nchild + 1)
-    uint32_t *d_keys_mid = nullptr; // level-2 output when there are 3 levels
+    uint32_t *d_keys_mid = nullptr;    // level-2 output when there are 3 levels
     uint64_t keys_mid_cap = 0;
-    uint16_t *d_keys_fin = nullptr; // last level output
+    uint16_t *d_keys_fin = nullptr;    // last level output
     uint64_t keys_fin_cap = 0;
-    uint32_t *d_merged = nullptr;   // all batches merged per level-1 bucket (only when > 1 batch)
+    uint32_t *d_merged = nullptr;      // all batches merged per level-1 bucket (only when > 1 batch)
     uint64_t merged_cap = 0;
     uint64_t *d_l1off_all = nullptr;
+    uint32_t *d_cnts = nullptr;        // B1 running counts (merge)
+    uint64_t *d_shift = nullptr;       // B1 (merge)
 };
 
 static int ensure_dev(void **p, uint64_t *cap, uint64_t need_bytes)
@@ -549,13 +668,14 @@ int part_begin(brx_counter *c)
     st->pl = make_plan(c->k);
     const Plan &pl = st->pl;
     hipError_t e = hipMalloc((void **)&st->d_scalars, 16);
-    for (int l = 0; l < pl.nlev && e == hipSuccess; l++) {
-        e = hipMalloc((void **)&st->d_hist[l], pl.nchild[l] * 2 * 4);
-        if (e == hipSuccess)
-            e = hipMalloc((void **)&st->d_coff[l], (pl.nchild[l] + 1) * 8);
-    }
+    for (int l = 0; l < pl.nlev && e == hipSuccess; l++)
+        e = hipMalloc((void **)&st->d_coff[l], (pl.nchild[l] + 1) * 8);
     if (e == hipSuccess)
         e = hipMalloc((void **)&st->d_l1off_all, (pl.nchild[0] + 1) * 8);
+    if (e == hipSuccess)
+        e = hipMalloc((void **)&st->d_cnts, (pl.nchild[0] + 1) * 4);
+    if (e == hipSuccess)
+        e = hipMalloc((void **)&st->d_shift, (pl.nchild[0] + 1) * 8);
     if (e != hipSuccess) {
         set_error("partition state alloc: %s", hipGetErrorString(e));
         return BRX_ERR_NOMEM;
@@ -575,10 +695,10 @@ void part_free(brx_counter *c)
             if (b.d_l1off)
                 (void)hipFree(b.d_l1off);
         }
-    for (void *p : {(void *)st->d_ntiles, (void *)st->d_item_off, (void *)st->d_item_parent, (void *)st->d_scan_tmp, (void *)st->d_scalars,
-                    (void *)st->d_hist[0], (void *)st->d_hist[1], (void *)st->d_hist[2], (void *)st->d_coff[0],
+    for (void *p : {(void *)st->d_ntiles, (void *)st->d_item_off, (void *)st->d_item_parent, (void *)st->d_matrix,
+                    (void *)st->d_pos, (void *)st->d_scan_tmp, (void *)st->d_scalars, (void *)st->d_coff[0],
                     (void *)st->d_coff[1], (void *)st->d_coff[2], (void *)st->d_keys_mid, (void *)st->d_keys_fin,
-                    (void *)st->d_merged, (void *)st->d_l1off_all})
+                    (void *)st->d_merged, (void *)st->d_l1off_all, (void *)st->d_cnts, (void *)st->d_shift})
         if (p)
             (void)hipFree(p);
     delete st;
@@ -594,22 +714,17 @@ int part_reset(brx_counter *c)
     return BRX_OK;
 }
 
-static int ensure_tables(PartState *st, uint64_t n_parents, uint64_t nchild, uint64_t max_items = 0)
+// matrix / pos / scan scratch for `n_entries` per-tile counters
+static int ensure_matrix(PartState *st, uint64_t n_entries)
 {
-    if (max_items) {
-        uint64_t capi = st->item_parent_cap;
-        BRX_TRY(ensure_dev((void **)&st->d_item_parent, &capi, (max_items + 1) * 4));
-        st->item_parent_cap = capi;
-    }
-    uint64_t capb = st->ntiles_cap;
-    BRX_TRY(ensure_dev((void **)&st->d_ntiles, &capb, (n_parents + 1) * 4));
-    st->ntiles_cap = capb;
-    capb = st->item_off_cap;
-    BRX_TRY(ensure_dev((void **)&st->d_item_off, &capb, (n_parents + 2) * 8));
-    st->item_off_cap = capb;
+    uint64_t capb = st->matrix_cap;
+    BRX_TRY(ensure_dev((void **)&st->d_matrix, &capb, (n_entries + 1) * 4));
+    st->matrix_cap = capb;
+    capb = st->pos_cap;
+    BRX_TRY(ensure_dev((void **)&st->d_pos, &capb, (n_entries + 2) * 8));
+    st->pos_cap = capb;
     capb = st->scan_tmp_cap;
-    const uint64_t big = n_parents > nchild ? n_parents : nchild;
-    BRX_TRY(ensure_dev((void **)&st->d_scan_tmp, &capb, scan_tmp_bytes((uint32_t)big) + 64));
+    BRX_TRY(ensure_dev((void **)&st->d_scan_tmp, &capb, scan_tmp_bytes((uint32_t)n_entries) + 64));
     st->scan_tmp_cap = capb;
     return BRX_OK;
 }
@@ -620,64 +735,13 @@ static size_t scatter_lds_bytes(uint32_t tile, int bits)
     return (size_t)tile * 6 + B * 8 + B * 12 + 64;
 }
 
-// runs one level: work-item table -> histogram -> scan -> scatter
-template <typename OUT>
-static int run_level(PartState *st, int l, bool from_bases, LevelArgs a, uint64_t n_parents, uint64_t max_keys, void *keys_out,
-                     hipStream_t s, const char *tag_hist, const char *tag_scatter, uint64_t *coff_out)
-{
-    const Plan &pl = st->pl;
-    const uint64_t nchild = pl.nchild[l];
-    uint32_t *hist = st->d_hist[l], *cursor = st->d_hist[l] + nchild;
-    const uint32_t tile = (pl.bits[l] > 8) ? 8192u : 4096u;
-    BRX_TRY(ensure_tables(st, n_parents, nchild, max_keys / tile + n_parents + 1));
-    a.tile = tile;
-    a.rem_in = pl.rem_in[l];
-    a.bits = pl.bits[l];
-    a.hier = (l > 0) ? 1 : 0;
-    a.hist = hist;
-    a.coff = coff_out;
-    a.cursor = cursor;
-    a.keys_out = keys_out;
-    a.n_parents = n_parents;
-    a.item_off = st->d_item_off;
-    a.n_items = st->d_scalars;
-    if (from_bases)
-        tiles_from_reads_kernel<<<(unsigned)((n_parents + 255) / 256), 256, 0, s>>>(a.offsets, (uint32_t)n_parents, a.k, tile,
-                                                                                   st->d_ntiles);
-    else
-        tiles_from_offsets_kernel<<<(unsigned)((n_parents + 255) / 256), 256, 0, s>>>(a.poff, n_parents, tile, st->d_ntiles);
-    BRX_TRY(exclusive_scan_lens(st->d_ntiles, (uint32_t)n_parents, st->d_scan_tmp, st->d_item_off, st->d_scalars, s));
-    fill_item_parent_kernel<<<(unsigned)((n_parents + 255) / 256), 256, 0, s>>>(st->d_item_off, n_parents, st->d_item_parent);
-    a.item_parent = st->d_item_parent;
-    BRX_HIP(hipMemsetAsync(hist, 0, nchild * 2 * 4, s));
-    const int grid = 256 * 8;
-    const size_t B = (size_t)1 << a.bits;
-    {
-        KernelTimer t(tag_hist, s);
-        if (from_bases)
-            level_hist_kernel<true><<<grid, 256, B * 4, s>>>(a);
-        else
-            level_hist_kernel<false><<<grid, 256, B * 4, s>>>(a);
-    }
-    // child offsets; the scan's grand total lands in d_scalars[1]
-    BRX_TRY(exclusive_scan_lens(hist, (uint32_t)nchild, st->d_scan_tmp, coff_out, st->d_scalars + 1, s));
-    {
-        KernelTimer t(tag_scatter, s);
-        const size_t lds = scatter_lds_bytes(tile, a.bits);
-        if (from_bases)
-            level_scatter_kernel<true, OUT><<<grid, 256, lds, s>>>(a);
-        else
-            level_scatter_kernel<false, OUT><<<grid, 256, lds, s>>>(a);
-    }
-    BRX_HIP(hipGetLastError());
-    return BRX_OK;
-}
-
 int part_add_batch(brx_counter *c, const uint8_t *d_bases, const uint64_t *d_offsets, uint32_t n_reads,
                    uint64_t total_bases, hipStream_t s)
 {
     PartState *st = c->part;
     const Plan &pl = st->pl;
+    if (total_bases == 0 || n_reads == 0)
+        return BRX_OK;
     const uint64_t max_keys = total_bases; // upper bound of the number of k-mers of this batch
     PartBatch b;
     for (size_t i = 0; i < st->spare.size(); i++)
@@ -692,17 +756,115 @@ int part_add_batch(brx_counter *c, const uint8_t *d_bases, const uint64_t *d_off
         b.cap = capb / 4;
         BRX_HIP(hipMalloc((void **)&b.d_l1off, (pl.nchild[0] + 1) * 8));
     }
-    LevelArgs a;
+    const uint32_t B = 1u << pl.bits[0];
+    const uint64_t n_items64 = (total_bases + L1_TILE - 1) / L1_TILE;
+    if (n_items64 * B >= (1ull << 32)) {
+        set_error("batch of %llu bases is too large for one partition pass; split it", (unsigned long long)total_bases);
+        return BRX_ERR_UNSUPPORTED;
+    }
+    const uint32_t n_items = (uint32_t)n_items64;
+    const uint64_t n_entries = (uint64_t)B * n_items;
+    BRX_TRY(ensure_matrix(st, n_entries));
+    L1Args a;
     memset(&a, 0, sizeof(a));
     a.bases = d_bases;
     a.offsets = d_offsets;
+    a.n_reads = n_reads;
+    a.total = total_bases;
+    a.n_items = n_items;
     a.k = pl.k;
-    BRX_TRY(run_level<uint32_t>(st, 0, true, a, n_reads, max_keys, b.d_keys, s, "part_l1_hist", "part_l1_scatter", b.d_l1off));
+    a.nbits = pl.nbits;
+    a.bits = pl.bits[0];
+    a.matrix = st->d_matrix;
+    a.pos = st->d_pos;
+    a.keys_out = b.d_keys;
+    const int grid = n_items < 2048u ? (int)n_items : 2048;
+    {
+        KernelTimer t("part_l1_hist", s);
+        l1_hist_kernel<<<grid, 256, (size_t)B * 4, s>>>(a);
+    }
+    BRX_TRY(exclusive_scan_lens(st->d_matrix, (uint32_t)n_entries, st->d_scan_tmp, st->d_pos, st->d_scalars + 1, s));
+    l1_coff_kernel<<<(B + 1 + 255) / 256, 256, 0, s>>>(st->d_pos, B, n_items, b.d_l1off);
+    {
+        KernelTimer t("part_l1_scatter", s);
+        l1_scatter_kernel<<<grid, 256, scatter_lds_bytes(L1_TILE, a.bits), s>>>(a);
+    }
+    BRX_HIP(hipGetLastError());
     unsigned long long tot = 0;
     BRX_HIP(hipMemcpyAsync(&tot, st->d_scalars + 1, 8, hipMemcpyDeviceToHost, s));
     BRX_HIP(hipStreamSynchronize(s));
     b.n = tot;
     st->batches.push_back(b);
+    return BRX_OK;
+}
+
+// one level >= 2: work items -> per-tile histograms -> scan -> scatter -> child offsets
+template <typename OUT>
+static int run_level(PartState *st, int l, const uint32_t *keys_in, const uint64_t *poff, uint64_t n_parents, uint64_t total,
+                     void *keys_out, hipStream_t s, const char *tag_hist, const char *tag_scatter)
+{
+    const Plan &pl = st->pl;
+    const uint32_t B = 1u << pl.bits[l];
+    const uint32_t tile = (pl.bits[l] > 8) ? 8192u : 4096u;
+    const uint64_t ub_items = total / tile + n_parents + 1;
+    const uint64_t n_entries = (uint64_t)B * ub_items;
+    if (n_entries >= (1ull << 32)) {
+        set_error("partition level %d needs %llu tile counters; split the input into smaller counters", l + 1,
+                  (unsigned long long)n_entries);
+        return BRX_ERR_UNSUPPORTED;
+    }
+    {
+        uint64_t capb = st->ntiles_cap;
+        BRX_TRY(ensure_dev((void **)&st->d_ntiles, &capb, (n_parents + 1) * 4));
+        st->ntiles_cap = capb;
+        capb = st->item_off_cap;
+        BRX_TRY(ensure_dev((void **)&st->d_item_off, &capb, (n_parents + 2) * 8));
+        st->item_off_cap = capb;
+        capb = st->item_parent_cap;
+        BRX_TRY(ensure_dev((void **)&st->d_item_parent, &capb, (ub_items + 1) * 4));
+        st->item_parent_cap = capb;
+    }
+    BRX_TRY(ensure_matrix(st, n_entries > n_parents ? n_entries : n_parents));
+    tiles_from_offsets_kernel<<<(unsigned)((n_parents + 255) / 256), 256, 0, s>>>(poff, n_parents, tile, st->d_ntiles);
+    BRX_TRY(exclusive_scan_lens(st->d_ntiles, (uint32_t)n_parents, st->d_scan_tmp, st->d_item_off, st->d_scalars, s));
+    fill_item_parent_kernel<<<(unsigned)((n_parents + 255) / 256), 256, 0, s>>>(st->d_item_off, n_parents, st->d_item_parent);
+    BRX_HIP(hipMemsetAsync(st->d_matrix, 0, n_entries * 4, s));
+    LnArgs a;
+    memset(&a, 0, sizeof(a));
+    a.keys_in = keys_in;
+    a.poff = poff;
+    a.n_parents = n_parents;
+    a.item_off = st->d_item_off;
+    a.item_parent = st->d_item_parent;
+    a.n_items = st->d_scalars;
+    a.tile = tile;
+    a.rem_in = pl.rem_in[l];
+    a.bits = pl.bits[l];
+    a.matrix = st->d_matrix;
+    a.pos = st->d_pos;
+    a.keys_out = keys_out;
+    const int grid = 256 * 8;
+    {
+        KernelTimer t(tag_hist, s);
+        if (tile == 8192u)
+            ln_hist_kernel<32><<<grid, 256, (size_t)B * 4, s>>>(a);
+        else
+            ln_hist_kernel<16><<<grid, 256, (size_t)B * 4, s>>>(a);
+    }
+    BRX_TRY(exclusive_scan_lens(st->d_matrix, (uint32_t)n_entries, st->d_scan_tmp, st->d_pos, st->d_scalars + 1, s));
+    {
+        const uint64_t nc = n_parents * B + 1;
+        ln_coff_kernel<<<(unsigned)((nc + 255) / 256), 256, 0, s>>>(st->d_pos, st->d_item_off, n_parents, B, st->d_coff[l]);
+    }
+    {
+        KernelTimer t(tag_scatter, s);
+        const size_t lds = scatter_lds_bytes(tile, a.bits);
+        if (tile == 8192u)
+            ln_scatter_kernel<32, OUT><<<grid, 256, lds, s>>>(a);
+        else
+            ln_scatter_kernel<16, OUT><<<grid, 256, lds, s>>>(a);
+    }
+    BRX_HIP(hipGetLastError());
     return BRX_OK;
 }
 
@@ -717,7 +879,7 @@ int part_finish_into(brx_counter *c, uint32_t abundance, hipStream_t s, brx_set 
 
     const uint32_t *keys1 = nullptr;
     const uint64_t *l1off = nullptr;
-    if (st->batches.empty()) {
+    if (st->batches.empty() || total == 0) {
         BRX_HIP(hipMemsetAsync(dst->d_bits, 0, dst->nwords * 4, s));
         return BRX_OK;
     } else if (st->batches.size() == 1) {
@@ -727,17 +889,15 @@ int part_finish_into(brx_counter *c, uint32_t abundance, hipStream_t s, brx_set 
         uint64_t capb = st->merged_cap;
         BRX_TRY(ensure_dev((void **)&st->d_merged, &capb, (total + 1) * 4));
         st->merged_cap = capb;
-        BRX_TRY(ensure_tables(st, B1, B1));
-        uint32_t *cnts = st->d_hist[0];              // B1 running counts (the level-1 histogram is free again)
-        uint64_t *shift = (uint64_t *)st->d_coff[0]; // B1 u64 scratch
-        BRX_HIP(hipMemsetAsync(cnts, 0, (uint64_t)B1 * 4, s));
+        BRX_TRY(ensure_matrix(st, B1 + 1));
+        BRX_HIP(hipMemsetAsync(st->d_cnts, 0, (uint64_t)B1 * 4, s));
         for (auto &b : st->batches)
-            add_counts_kernel<<<(B1 + 255) / 256, 256, 0, s>>>(b.d_l1off, B1, cnts, nullptr);
-        BRX_TRY(exclusive_scan_lens(cnts, B1, st->d_scan_tmp, st->d_l1off_all, st->d_scalars + 1, s));
-        BRX_HIP(hipMemsetAsync(cnts, 0, (uint64_t)B1 * 4, s));
+            add_counts_kernel<<<(B1 + 255) / 256, 256, 0, s>>>(b.d_l1off, B1, st->d_cnts, nullptr);
+        BRX_TRY(exclusive_scan_lens(st->d_cnts, B1, st->d_scan_tmp, st->d_l1off_all, st->d_scalars + 1, s));
+        BRX_HIP(hipMemsetAsync(st->d_cnts, 0, (uint64_t)B1 * 4, s));
         for (auto &b : st->batches) {
-            add_counts_kernel<<<(B1 + 255) / 256, 256, 0, s>>>(b.d_l1off, B1, cnts, shift);
-            merge_segments_kernel<<<B1 < 4096u ? B1 : 4096u, 256, 0, s>>>(b.d_keys, b.d_l1off, st->d_l1off_all, shift, B1,
+            add_counts_kernel<<<(B1 + 255) / 256, 256, 0, s>>>(b.d_l1off, B1, st->d_cnts, st->d_shift);
+            merge_segments_kernel<<<B1 < 4096u ? B1 : 4096u, 256, 0, s>>>(b.d_keys, b.d_l1off, st->d_l1off_all, st->d_shift, B1,
                                                                          st->d_merged);
         }
         keys1 = st->d_merged;
@@ -749,28 +909,19 @@ int part_finish_into(brx_counter *c, uint32_t abundance, hipStream_t s, brx_set 
         BRX_TRY(ensure_dev((void **)&st->d_keys_fin, &capb, (total + 64) * 2));
         st->keys_fin_cap = capb;
     }
-    LevelArgs a;
-    memset(&a, 0, sizeof(a));
-    a.k = pl.k;
     const uint64_t *fin_off = nullptr;
     if (pl.nlev == 2) {
-        a.keys_in = keys1;
-        a.poff = l1off;
-        BRX_TRY(run_level<uint16_t>(st, 1, false, a, pl.nchild[0], total, st->d_keys_fin, s, "part_l2_hist", "part_l2_scatter",
-                                    st->d_coff[1]));
+        BRX_TRY(run_level<uint16_t>(st, 1, keys1, l1off, pl.nchild[0], total, st->d_keys_fin, s, "part_l2_hist",
+                                    "part_l2_scatter"));
         fin_off = st->d_coff[1];
     } else {
         uint64_t capb = st->keys_mid_cap;
         BRX_TRY(ensure_dev((void **)&st->d_keys_mid, &capb, (total + 64) * 4));
         st->keys_mid_cap = capb;
-        a.keys_in = keys1;
-        a.poff = l1off;
-        BRX_TRY(run_level<uint32_t>(st, 1, false, a, pl.nchild[0], total, st->d_keys_mid, s, "part_l2_hist", "part_l2_scatter",
-                                    st->d_coff[1]));
-        a.keys_in = st->d_keys_mid;
-        a.poff = st->d_coff[1];
-        BRX_TRY(run_level<uint16_t>(st, 2, false, a, pl.nchild[1], total, st->d_keys_fin, s, "part_l3_hist", "part_l3_scatter",
-                                    st->d_coff[2]));
+        BRX_TRY(run_level<uint32_t>(st, 1, keys1, l1off, pl.nchild[0], total, st->d_keys_mid, s, "part_l2_hist",
+                                    "part_l2_scatter"));
+        BRX_TRY(run_level<uint16_t>(st, 2, st->d_keys_mid, st->d_coff[1], pl.nchild[1], total, st->d_keys_fin, s,
+                                    "part_l3_hist", "part_l3_scatter"));
         fin_off = st->d_coff[2];
     }
     {
