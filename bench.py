@@ -40,6 +40,8 @@ def parse():
     ap.add_argument("--coverage", type=int, default=50)
     ap.add_argument("--strategy", default="auto", choices=["auto", "dense", "sorted"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-exchange", action="store_true",
+                    help="debug: run the multi-GPU exchange step even with one rank (RCCL, world_size 1)")
     ap.add_argument("--cpu-reads", type=int, default=0, help="reads in the CPU-baseline sample (0 = auto)")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic_latest.json"),
                     help="optional PMC-derived HBM bytes per launch, produced by profiles/collect_pmc.sh")
@@ -63,8 +65,10 @@ def main():
 
     torch.cuda.set_device(local_rank)
     dev = local_rank
-    if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if world > 1 or args.force_exchange:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     stream = torch.cuda.current_stream().cuda_stream
 
     k, a = args.k, args.abundance
@@ -89,7 +93,10 @@ def main():
     chain = br_amd.Chain(gs, [("one", args.confirm, 7)], two_side=False)
 
     from br_amd import dist as brx_dist
-    exchanger = brx_dist.SetExchange(world, rank) if world > 1 else None
+    multi = world > 1 or args.force_exchange
+    exchanger = brx_dist.SetExchange(world, rank) if multi else None
+    partitioned = multi and (args.strategy == "sorted" or (args.strategy == "auto" and k >= 15))
+    owned = br_amd.Counter(k, dev, _lib.COUNT_SORTED) if partitioned else None
 
     phase_ms = {"build": 0.0, "correct": 0.0}
 
@@ -97,9 +104,12 @@ def main():
         t0 = time.perf_counter()
         counter.reset(stream)
         counter.add_batch_device(d_bases.data_ptr(), d_off.data_ptr(), n_reads, total, stream)
-        if exchanger is not None:
-            exchanger.reduce_counts(counter, a, stream)
-        counter.finish_into(a, gs, stream)
+        if exchanger is not None and partitioned:
+            exchanger.build_partitioned(counter, owned, gs, a, stream)   # keys to their owner, solid set back
+        else:
+            if exchanger is not None:
+                exchanger.reduce_counts(counter, a, stream)              # dense: u8 all-reduce
+            counter.finish_into(a, gs, stream)
         if timed:
             torch.cuda.synchronize()
         t1 = time.perf_counter()
@@ -205,7 +215,7 @@ def main():
             "cpu_baseline": cpu,
         }
         print(json.dumps(line))
-    if world > 1:
+    if world > 1 or args.force_exchange:
         dist.destroy_process_group()
 
 

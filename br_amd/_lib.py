@@ -59,6 +59,8 @@ SIGNATURES = {
     "brx_set_export_solid_bytes": (C.c_int, [_vp, _vp, C.c_size_t, C.POINTER(C.c_size_t)]),
     "brx_set_popcount": (C.c_int, [_vp, _u64p]),
     "brx_set_device_bits": (C.c_int, [_vp, _pp, _u64p]),
+    "brx_set_extract_keys_device": (C.c_int, [_vp, C.c_uint64, C.c_uint64, _vp, C.c_uint64, _u64p, _vp]),
+    "brx_set_or_keys_device": (C.c_int, [_vp, _vp, C.c_uint64, _vp]),
     "brx_set_free": (None, [_vp]),
     "brx_set_count_begin": (C.c_int, [C.c_uint8, C.c_int, C.c_int, _pp]),
     "brx_set_count_add_batch": (C.c_int, [_vp, _vp, _vp, C.c_uint32]),
@@ -68,8 +70,8 @@ SIGNATURES = {
     "brx_counter_reset": (C.c_int, [_vp, _vp]),
     "brx_counter_device_counts": (C.c_int, [_vp, _pp, _u64p]),
     "brx_counter_clamp": (C.c_int, [_vp, C.c_uint8, _vp]),
-    "brx_counter_device_keys": (C.c_int, [_vp, _pp, _u64p]),
-    "brx_counter_add_keys_device": (C.c_int, [_vp, _vp, C.c_uint64, _vp]),
+    "brx_counter_l1_view": (C.c_int, [_vp, _pp, _pp, C.POINTER(C.c_uint32), _u64p]),
+    "brx_counter_add_partitioned_device": (C.c_int, [_vp, _vp, _vp, C.c_uint64]),
     "brx_counter_free": (None, [_vp]),
     "brx_chain_new": (C.c_int, [_vp, C.POINTER(Method), C.c_uint32, C.c_bool, _pp]),
     "brx_chain_correct_batch": (C.c_int, [_vp, _vp, _vp, C.c_uint32, C.POINTER(_u8p), C.POINTER(_u64p)]),

@@ -167,7 +167,7 @@ __device__ __forceinline__ uint32_t two_correct(const TwoCtx &t, int sc, uint64_
 // Affine gaps (open -1, extend -1), match +1 / mismatch -1, no clipping; `>`-only updates in the
 // order match/subst, ins, del; traceback through per-layer back pointers; Ins consumes x, Del y.
 // Restated from the crate's published algorithm (source not in the container; tie-breaks unpinned,
-// SURVEY H3) -- the same restatement as oracle/br_oracle.c:bio_global, laid out as a systolic
+// SURVEY H3) -- the same restatement the CPU checker uses, laid out here as a systolic
 // anti-diagonal sweep: lane l of the group owns DP row band*G+l+1, row values travel to the next
 // lane by shuffle, the back-pointer matrix lives in LDS.
 enum { TBV_START = 0, TBV_INS = 1, TBV_DEL = 2, TBV_SUBST = 3, TBV_MATCH = 4, TBV_XCLIP = 5 };

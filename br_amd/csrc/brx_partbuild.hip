@@ -606,6 +606,7 @@ struct PartBatch {
     uint32_t *d_keys = nullptr;  // keys after level 1, grouped by digit 1
     uint64_t cap = 0, n = 0;
     uint64_t *d_l1off = nullptr; // B1 + 1
+    bool borrowed = false;       // memory owned by the caller (segments received from other ranks)
 };
 
 } // namespace
@@ -690,6 +691,8 @@ void part_free(brx_counter *c)
         return;
     for (auto *v : {&st->batches, &st->spare})
         for (auto &b : *v) {
+            if (b.borrowed)
+                continue;
             if (b.d_keys)
                 (void)hipFree(b.d_keys);
             if (b.d_l1off)
@@ -709,8 +712,41 @@ int part_reset(brx_counter *c)
 {
     PartState *st = c->part;
     for (auto &b : st->batches)
-        st->spare.push_back(b);
+        if (!b.borrowed)
+            st->spare.push_back(b);
     st->batches.clear();
+    return BRX_OK;
+}
+
+// level-1 output of the (single) local batch: keys grouped by their first digit + bucket offsets
+int part_l1_view(brx_counter *c, void **d_keys, void **d_l1off, uint32_t *n_buckets, uint64_t *n_keys)
+{
+    PartState *st = c->part;
+    *n_buckets = (uint32_t)st->pl.nchild[0];
+    if (st->batches.size() != 1 || st->batches[0].borrowed) {
+        set_error("l1_view needs exactly one locally counted batch (have %zu)", st->batches.size());
+        return BRX_ERR_ARG;
+    }
+    *d_keys = st->batches[0].d_keys;
+    *d_l1off = st->batches[0].d_l1off;
+    *n_keys = st->batches[0].n;
+    return BRX_OK;
+}
+
+// registers a level-1 segment produced elsewhere (another rank); the memory stays the caller's and
+// must outlive finish
+int part_add_partitioned(brx_counter *c, const uint32_t *d_keys, const uint64_t *d_l1off, uint64_t n_keys)
+{
+    PartState *st = c->part;
+    if (n_keys == 0)
+        return BRX_OK;
+    PartBatch b;
+    b.d_keys = const_cast<uint32_t *>(d_keys);
+    b.d_l1off = const_cast<uint64_t *>(d_l1off);
+    b.n = n_keys;
+    b.cap = n_keys;
+    b.borrowed = true;
+    st->batches.push_back(b);
     return BRX_OK;
 }
 

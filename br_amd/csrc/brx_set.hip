@@ -151,6 +151,50 @@ __global__ __launch_bounds__(256) void popcount_kernel(const uint32_t *__restric
         atomicAdd(total, acc);
 }
 
+// compacts the set bits of words [w0, w0+nw) into a list of absolute bit indices (any order)
+__global__ __launch_bounds__(256) void extract_kernel(const uint32_t *__restrict__ bits, uint64_t w0, uint64_t nw,
+                                                      unsigned long long *__restrict__ counter, uint64_t *__restrict__ out,
+                                                      uint64_t cap)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    const int lane = threadIdx.x & 63;
+    for (uint64_t i0 = (uint64_t)blockIdx.x * blockDim.x; i0 < nw; i0 += stride) {
+        const uint64_t i = i0 + threadIdx.x;
+        uint32_t w = i < nw ? bits[w0 + i] : 0u;
+        const uint32_t n = __popc(w);
+        // wave-inclusive scan of n, one atomic per wave
+        uint32_t incl = n;
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t t = __shfl_up(incl, d);
+            if (lane >= d)
+                incl += t;
+        }
+        const uint32_t wave_total = __shfl(incl, 63);
+        unsigned long long base = 0;
+        if (lane == 63 && wave_total)
+            base = atomicAdd(counter, (unsigned long long)wave_total);
+        base = __shfl(base, 63);
+        unsigned long long pos = base + incl - n;
+        while (w) {
+            const int b = __ffs(w) - 1;
+            w &= w - 1u;
+            if (pos < cap)
+                out[pos] = ((w0 + i) << 5) + (uint64_t)b;
+            pos++;
+        }
+    }
+}
+
+__global__ void or_keys_kernel(uint32_t *__restrict__ bits, const uint64_t *__restrict__ keys, uint64_t n, uint64_t nbits)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint64_t h = keys[i];
+        if (h < nbits)
+            atomicOr(bits + (h >> 5), 1u << (h & 31u));
+    }
+}
+
 int check_k(int k, bool need_odd)
 {
     if (k < 1 || k > 31) {
@@ -212,6 +256,8 @@ int part_reset(brx_counter *c);
 int part_add_batch(brx_counter *c, const uint8_t *d_bases, const uint64_t *d_offsets, uint32_t n_reads,
                    uint64_t total_bases, hipStream_t s);
 int part_finish_into(brx_counter *c, uint32_t abundance, hipStream_t s, brx_set *dst);
+int part_l1_view(brx_counter *c, void **d_keys, void **d_l1off, uint32_t *n_buckets, uint64_t *n_keys);
+int part_add_partitioned(brx_counter *c, const uint32_t *d_keys, const uint64_t *d_l1off, uint64_t n_keys);
 // used by the correction chain and the host-pointer entry points
 int upload_batch(const uint8_t *bases, const uint64_t *offsets, uint32_t n_reads, uint8_t **d_bases, uint64_t *bases_cap,
                  uint64_t **d_off, uint64_t *off_cap, uint64_t *total, hipStream_t stream)
@@ -628,22 +674,82 @@ int brx_counter_clamp(brx_counter_t *c, uint8_t cap, void *stream)
     return BRX_OK;
 }
 
-int brx_counter_device_keys(brx_counter_t *c, void **d_keys, uint64_t *n_keys)
+int brx_counter_l1_view(brx_counter_t *c, void **d_keys, void **d_l1off, uint32_t *n_buckets, uint64_t *n_keys)
 {
-    if (!c || !d_keys || !n_keys)
+    if (!c || !d_keys || !d_l1off || !n_buckets || !n_keys)
         return BRX_ERR_ARG;
-    set_error("sorted strategy not implemented");
-    return BRX_ERR_UNSUPPORTED;
+    if (c->strategy != BRX_COUNT_SORTED) {
+        set_error("l1_view: counter is not partitioned");
+        return BRX_ERR_ARG;
+    }
+    return part_l1_view(c, d_keys, d_l1off, n_buckets, n_keys);
 }
 
-int brx_counter_add_keys_device(brx_counter_t *c, const uint64_t *d_keys, uint64_t n_keys, void *stream)
+int brx_counter_add_partitioned_device(brx_counter_t *c, const uint32_t *d_keys, const uint64_t *d_l1off, uint64_t n_keys)
 {
-    (void)c;
-    (void)d_keys;
-    (void)n_keys;
-    (void)stream;
-    set_error("sorted strategy not implemented");
-    return BRX_ERR_UNSUPPORTED;
+    if (!c || (!d_keys && n_keys) || !d_l1off)
+        return BRX_ERR_ARG;
+    if (c->strategy != BRX_COUNT_SORTED) {
+        set_error("add_partitioned: counter is not partitioned");
+        return BRX_ERR_ARG;
+    }
+    return part_add_partitioned(c, d_keys, d_l1off, n_keys);
+}
+
+int brx_set_extract_keys_device(const brx_set_t *set, uint64_t first_hash, uint64_t n_hashes, uint64_t *d_out, uint64_t cap,
+                                uint64_t *n_out, void *stream)
+{
+    if (!set || !n_out || (!d_out && cap)) {
+        set_error("null argument");
+        return BRX_ERR_ARG;
+    }
+    const uint64_t nbits = set->nwords * 32;
+    if ((first_hash & 31u) || (n_hashes & 31u) || first_hash + n_hashes > nbits) {
+        set_error("extract range must be 32-aligned and inside the set");
+        return BRX_ERR_ARG;
+    }
+    BRX_TRY(use_device(set->device));
+    hipStream_t s = (hipStream_t)stream;
+    unsigned long long *d_cnt = nullptr;
+    BRX_HIP(hipMalloc((void **)&d_cnt, 8));
+    hipError_t e = hipMemsetAsync(d_cnt, 0, 8, s);
+    const uint64_t nw = n_hashes / 32;
+    if (e == hipSuccess && nw) {
+        KernelTimer t("extract_keys", s);
+        extract_kernel<<<grid_for(nw, 256, 256 * 8), 256, 0, s>>>(set->d_bits, first_hash / 32, nw, d_cnt, d_out, cap);
+    }
+    unsigned long long n = 0;
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(&n, d_cnt, 8, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess)
+        e = hipStreamSynchronize(s);
+    (void)hipFree(d_cnt);
+    if (e != hipSuccess) {
+        set_error("extract: %s", hipGetErrorString(e));
+        return BRX_ERR_HIP;
+    }
+    *n_out = n;
+    if (n > cap) {
+        set_error("extract found %llu keys, buffer holds %llu", n, (unsigned long long)cap);
+        return BRX_ERR_OVERFLOW;
+    }
+    return BRX_OK;
+}
+
+int brx_set_or_keys_device(brx_set_t *set, const uint64_t *d_keys, uint64_t n, void *stream)
+{
+    if (!set || (!d_keys && n))
+        return BRX_ERR_ARG;
+    BRX_TRY(use_device(set->device));
+    if (!n)
+        return BRX_OK;
+    hipStream_t s = (hipStream_t)stream;
+    {
+        KernelTimer t("or_keys", s);
+        or_keys_kernel<<<grid_for(n, 256, 256 * 8), 256, 0, s>>>(set->d_bits, d_keys, n, set->nwords * 32);
+    }
+    BRX_HIP(hipGetLastError());
+    return BRX_OK;
 }
 
 void brx_counter_free(brx_counter_t *c)

@@ -153,6 +153,17 @@ class Pcon(KmerSet):
         _lib.check(_lib.lib().brx_set_device_bits(self._h, C.byref(p), C.byref(n)))
         return p.value, n.value
 
+    def n_hashes(self) -> int:
+        return max(1 << (2 * self.k() - 1), 32)
+
+    def extract_keys_device(self, first_hash: int, n_hashes: int, d_out: int, cap: int, stream: Optional[int] = None) -> int:
+        n = C.c_uint64(0)
+        _lib.check(_lib.lib().brx_set_extract_keys_device(self._h, first_hash, n_hashes, d_out, cap, C.byref(n), stream))
+        return n.value
+
+    def or_keys_device(self, d_keys: int, n: int, stream: Optional[int] = None) -> None:
+        _lib.check(_lib.lib().brx_set_or_keys_device(self._h, d_keys, n, stream))
+
 
 class Counter:
     """pcon::counter::Counter<u8> as used by `br fasta` (src/main.rs:73-78)."""
@@ -191,6 +202,15 @@ class Counter:
         p, n = C.c_void_p(), C.c_uint64(0)
         _lib.check(_lib.lib().brx_counter_device_counts(self._h, C.byref(p), C.byref(n)))
         return p.value, n.value
+
+    def l1_view(self) -> Tuple[int, int, int, int]:
+        """(d_keys, d_l1off, n_buckets, n_keys) of the single counted batch (partitioned strategy)."""
+        pk, po, nb, nk = C.c_void_p(), C.c_void_p(), C.c_uint32(0), C.c_uint64(0)
+        _lib.check(_lib.lib().brx_counter_l1_view(self._h, C.byref(pk), C.byref(po), C.byref(nb), C.byref(nk)))
+        return pk.value or 0, po.value or 0, nb.value, nk.value
+
+    def add_partitioned_device(self, d_keys: int, d_l1off: int, n_keys: int) -> None:
+        _lib.check(_lib.lib().brx_counter_add_partitioned_device(self._h, d_keys, d_l1off, n_keys))
 
     def reset(self, stream: Optional[int] = None) -> None:
         _lib.check(_lib.lib().brx_counter_reset(self._h, stream))

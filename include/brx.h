@@ -98,6 +98,11 @@ int brx_set_export_solid_bytes(const brx_set_t *set, uint8_t *buf, size_t cap, s
 int brx_set_popcount(const brx_set_t *set, uint64_t *n_set_bits);
 /* device view of the packed bit array (for RCCL all-gather / OR across ranks)              */
 int brx_set_device_bits(const brx_set_t *set, void **d_bits, uint64_t *n_bytes);
+/* sparse replication of the set: list the set bits of [first_hash, first_hash+n_hashes) (both
+ * multiples of 32) as absolute bit indices, any order; OR a list of bit indices into a set      */
+int brx_set_extract_keys_device(const brx_set_t *set, uint64_t first_hash, uint64_t n_hashes, uint64_t *d_out, uint64_t cap,
+                                uint64_t *n_out, void *stream);
+int brx_set_or_keys_device(brx_set_t *set, const uint64_t *d_keys, uint64_t n, void *stream);
 void brx_set_free(brx_set_t *set);
 
 /* ---- set build by counting: src/main.rs:72-115 -------------------------------------------
@@ -121,10 +126,13 @@ int brx_counter_reset(brx_counter_t *c, void *stream);
 int brx_counter_device_counts(brx_counter_t *c, void **d_counts, uint64_t *n_bytes);
 /* clamp every count to min(count, cap) in place (the exact-sum trick before an u8 all-reduce) */
 int brx_counter_clamp(brx_counter_t *c, uint8_t cap, void *stream);
-/* sorted strategy only: device view of the (unsorted) canonical-hash list gathered so far   */
-int brx_counter_device_keys(brx_counter_t *c, void **d_keys, uint64_t *n_keys);
-/* sorted strategy: append hashes produced elsewhere (e.g. received from another rank)       */
-int brx_counter_add_keys_device(brx_counter_t *c, const uint64_t *d_keys, uint64_t n_keys, void *stream);
+/* partitioned strategy, multi-GPU exchange (done on keys instead of the count vector):
+ * after ONE add_batch the canonical hashes sit grouped by their first radix digit.  l1_view exposes
+ * that layout (u32 keys with the digit stripped, u64 offsets[n_buckets+1]); a rank owns a contiguous
+ * range of buckets, receives the other ranks' segments of that range and registers them with
+ * add_partitioned (the memory stays the caller's until the counter is finished/reset).           */
+int brx_counter_l1_view(brx_counter_t *c, void **d_keys, void **d_l1off, uint32_t *n_buckets, uint64_t *n_keys);
+int brx_counter_add_partitioned_device(brx_counter_t *c, const uint32_t *d_keys, const uint64_t *d_l1off, uint64_t n_keys);
 void brx_counter_free(brx_counter_t *c);
 
 /* ---- correction: src/lib.rs:22-139 (run_correction) + src/correct/mod.rs:44-108 ----------

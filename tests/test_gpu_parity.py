@@ -406,3 +406,81 @@ def test_output_slot_overflow_retry():
         if method == "graph":
             assert got[0] == genome[100:370] and got[1] == genome[500:960]
             assert chain.last_stats()["overflow_retries"] >= 1
+
+
+def test_partitioned_exchange_primitives_two_shards(raw_reads):
+    """the data path of the multi-GPU key exchange, emulated on one GPU: two shards counted separately,
+    every 'owner' receives both shards' segments of its digit range (l1_view / add_partitioned), finishes
+    its range, and the solid set is replicated sparsely (extract_keys / or_keys).  Same bits as one build."""
+    import torch
+    from br_amd import dist as bd
+    k, a = 13, 2
+    reads = raw_reads[:60]
+    shards = [reads[:30], reads[30:]]
+    stream = torch.cuda.current_stream().cuda_stream
+    locals_ = []
+    for sh in shards:
+        c = br_amd.Counter(k, 0, _lib.COUNT_SORTED)
+        bases, offs = br_amd.pack_reads(sh)
+        db = torch.from_numpy(bases.copy()).cuda()
+        do = torch.from_numpy(offs.astype(np.int64)).cuda()
+        c.add_batch_device(db.data_ptr(), do.data_ptr(), len(sh), int(offs[-1]), stream)
+        locals_.append((c, db, do))
+    world = 2
+    final = br_amd.Pcon.new(k)
+    keep = []
+    per_owner_sets = []
+    for owner in range(world):
+        owned = br_amd.Counter(k, 0, _lib.COUNT_SORTED)
+        solid = br_amd.Pcon.new(k)
+        for c, _, _ in locals_:
+            pk, po, nb, nk = c.l1_view()
+            keys = bd.device_view(pk, max(nk, 1) * 4).view(torch.int32)[:nk]
+            t = bd.device_view(po, (nb + 1) * 8).view(torch.int64)
+            bounds = bd.owner_bounds(nb, world)
+            lo, hi = bounds[owner], bounds[owner + 1]
+            seg_keys = keys[int(t[lo]):int(t[hi])].clone()
+            seg_off = (t.clamp(min=t[lo], max=t[hi]) - t[lo]).contiguous()
+            keep.append((seg_keys, seg_off))
+            owned.add_partitioned_device(seg_keys.data_ptr(), seg_off.data_ptr(), seg_keys.numel())
+        owned.finish_into(a, solid, stream)
+        torch.cuda.synchronize()
+        per_bucket = solid.n_hashes() // nb
+        buf = torch.empty(1 << 20, dtype=torch.int64, device="cuda")
+        n = solid.extract_keys_device(lo * per_bucket, (hi - lo) * per_bucket, buf.data_ptr(), buf.numel(), stream)
+        final.or_keys_device(buf.data_ptr(), n, stream)
+        torch.cuda.synchronize()
+        per_owner_sets.append(n)
+    ref = O.Solid.from_count(k, O.count_reads(k, reads), a)
+    assert final.to_solid_bytes() == ref.to_bytes()
+    assert sum(per_owner_sets) == ref.popcount() and min(per_owner_sets) > 0
+
+
+def test_build_partitioned_over_rccl_single_rank(raw_reads):
+    """SetExchange.build_partitioned end to end on device tensors with the real "nccl" (RCCL) backend,
+    world_size 1 (the GPU box has one card; N > 1 is covered by the gloo tests and the emulation above)."""
+    import torch
+    import torch.distributed as dist
+    from br_amd import dist as bd
+    k, a = 15, 2
+    reads = raw_reads[:50]
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(29400 + os.getpid() % 300))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        stream = torch.cuda.current_stream().cuda_stream
+        local = br_amd.Counter(k, 0, _lib.COUNT_SORTED)
+        owned = br_amd.Counter(k, 0, _lib.COUNT_SORTED)
+        solid = br_amd.Pcon.new(k)
+        bases, offs = br_amd.pack_reads(reads)
+        db = torch.from_numpy(bases.copy()).cuda()
+        do = torch.from_numpy(offs.astype(np.int64)).cuda()
+        for _ in range(2):  # twice: the bench resets and reuses the same objects every step
+            local.reset(stream)
+            local.add_batch_device(db.data_ptr(), do.data_ptr(), len(reads), int(offs[-1]), stream)
+            bd.SetExchange(1, 0).build_partitioned(local, owned, solid, a, stream)
+            torch.cuda.synchronize()
+            ref = O.Solid.from_count(k, O.count_reads(k, reads), a)
+            assert solid.to_solid_bytes() == ref.to_bytes()
+    finally:
+        dist.destroy_process_group()
