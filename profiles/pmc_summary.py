@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Summarises the three PMC passes of profiles/collect_pmc.sh into profiles/<tag>_pmc_summary.json and
+profiles/traffic_latest.json (read by bench.py for roofline.traffic).
+
+Units/corrections (MI355X_MICROARCH.md, HBM section): FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950
+FETCH_SIZE counts 64 B per memory-side read request.  Calibration on this repo's own access pattern
+(tools/probe_bench under the same counter): random 4-byte loads -> 64 B per load as counted (one 64-B
+request each, no correction); float4 stream -> exactly half the bytes (128-B requests, x2 correction).
+correct_pass is >98 % random probes, so its FETCH_SIZE is used as counted; streaming kernels get x2."""
+import collections
+import csv
+import json
+import os
+import sys
+
+out_dir, tag = sys.argv[1], sys.argv[2]
+here = os.path.dirname(os.path.abspath(__file__))
+
+
+def load(path):
+    agg = collections.defaultdict(list)
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            agg[(r["Kernel_Name"], r["Counter_Name"])].append(float(r["Counter_Value"]))
+    return agg
+
+
+def find(d, sub, ctr):
+    return [v for (k, c), vs in d.items() if sub in k and c == ctr for v in vs]
+
+
+probe = load(os.path.join(out_dir, "probe", "p_counter_collection.csv"))
+fetch = load(os.path.join(out_dir, "fetch", "f_counter_collection.csv"))
+write = load(os.path.join(out_dir, "write", "w_counter_collection.csv"))
+
+cal_rand = max(find(probe, "rand_probe<4>", "FETCH_SIZE")) * 1024 / (8192 * 256 * 64)
+cal_stream = max(find(probe, "stream_read", "FETCH_SIZE")) * 1024 / (16 * 2 ** 30)
+
+line = None
+for ln in open(os.path.join(out_dir, "fetch.log")):
+    if ln.startswith("{"):
+        line = json.loads(ln)
+bases = line["config"]["bases_per_gpu"] if line else None
+
+STREAMING = ("l1_", "ln_", "final_count", "compact", "threshold", "lens_", "popcount")
+kern = {}
+for (k, c), vs in fetch.items():
+    kern.setdefault(k, {})["fetch_kib"] = vs
+for (k, c), vs in write.items():
+    kern.setdefault(k, {})["write_kib"] = vs
+summary = {}
+for k, d in kern.items():
+    short = k.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
+    f = d.get("fetch_kib", [0.0])
+    w = d.get("write_kib", [0.0])
+    corr = 2.0 if any(s in short for s in STREAMING) else 1.0
+    summary[short] = {"launches": max(len(f), len(w)), "fetch_bytes_per_launch_counted": sum(f) / len(f) * 1024,
+                      "fetch_correction": corr, "write_bytes_per_launch": sum(w) / len(w) * 1024,
+                      "hbm_bytes_per_launch": sum(f) / len(f) * 1024 * corr + sum(w) / len(w) * 1024}
+res = {"tag": tag, "calibration": {"random_4B_load_bytes_as_counted": cal_rand,
+                                   "stream_fraction_counted": cal_stream}, "bases_per_launch": bases, "kernels": summary}
+with open(os.path.join(here, f"{tag}_pmc_summary.json"), "w") as f:
+    json.dump(res, f, indent=1)
+ck = [v for k, v in summary.items() if k.startswith("correct_kernel<16, 0>") or k.startswith("correct_kernel<")]
+if ck and bases:
+    with open(os.path.join(here, "traffic_latest.json"), "w") as f:
+        json.dump({"kernel": "correct_pass", "bases_per_launch": bases, "hbm_bytes_per_launch": ck[0]["hbm_bytes_per_launch"],
+                   "source": f"profiles/{tag}_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"}, f)
+print(json.dumps(res["calibration"]), ck[0] if ck else None)
