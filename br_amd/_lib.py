@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libbrx.so")
+LIB_PATH = os.environ.get("BRX_LIB_PATH") or os.path.join(_HERE, "lib", "libbrx.so")  # override: A/B of builds
 
 BRX_OK = 0
 BRX_ERR_OVERFLOW = -7

@@ -62,6 +62,7 @@ struct PassParams {
     uint64_t *path_k;
     uint32_t maxpath;
     // greedy (greedy.rs): max_search and the per-group LDS carve-up for the alignment
+    uint32_t flags;       // tuning switches for A/B runs (BRX_TUNE): 1 no look-ahead reuse, 2 four ALTS probes, 4 unstaged SCEN
     int max_search;
     uint32_t g_dim;       // max (m+1), (n+1) of the DP = k + max_search + 2
     uint32_t g_lds_bytes; // bytes of dynamic LDS per group
@@ -311,6 +312,14 @@ __device__ bool greedy_align(const GreedyLds &L, int gl, int m, int n, int nb, i
     return false;
 }
 
+// look-ahead k-mers per scenario probed in the SCEN round that starts at look-ahead index `sub`
+__device__ __forceinline__ uint32_t scen_width(uint32_t sub, uint32_t c, int G, uint32_t flags)
+{
+    const uint32_t left = c - sub;
+    const uint32_t cap = (sub == 0u && !(flags & 4u)) ? 2u : (uint32_t)G / 3u;
+    return left < cap ? left : cap;
+}
+
 template <int G, int M>
 __global__ __launch_bounds__(256) void correct_kernel(PassParams p)
 {
@@ -388,10 +397,13 @@ __global__ __launch_bounds__(256) void correct_kernel(PassParams p)
             st = ST_INIT;
             i = 0;
             olen = 0;
+            kmer = 0;
+            prev = false;
             steps = 0;
             return;
         }
     };
+    // logical base j of the current read (the reverse pass reads the buffer back to front)
     auto ld = [&](uint32_t j) -> uint8_t { return in[p.flip ? (n - 1u - j) : j]; };
     auto finish = [&]() {
         if (gl == 0)
@@ -431,6 +443,25 @@ __global__ __launch_bounds__(256) void correct_kernel(PassParams p)
         const int nb = gl + 1;
         return (nb >= k) ? (val & mask) : (((carry << (2 * nb)) | val) & mask);
     };
+
+    // 2-bit codes of the first WB = min(G, 32) lanes of the group, lane 0's base in the top bits
+    constexpr int WB = G < 32 ? G : 32;
+    auto group_window = [&](uint64_t code) -> uint64_t {
+        uint64_t val = code;
+#pragma unroll
+        for (int d = 1; d < WB; d <<= 1) {
+            const uint64_t other = __shfl_up(val, d, G);
+            if (gl >= d)
+                val |= other << (2 * d);
+        }
+        return __shfl(val, gshift + WB - 1);
+    };
+    // km extended by the window bases b0 .. b0+nb-1 (b0 + nb <= WB, nb <= 31)
+    auto ext = [&](uint64_t km, uint64_t W, uint32_t b0, uint32_t nb) -> uint64_t {
+        const uint64_t bits = (W >> (2u * ((uint32_t)WB - b0 - nb))) & ((1ull << (2u * nb)) - 1ull);
+        return ((km << (2u * nb)) | bits) & mask;
+    };
+    uint64_t win = 0; // bases seq[i .. i+WB) at the current trigger
 
     fetch();
 
@@ -477,19 +508,34 @@ __global__ __launch_bounds__(256) void correct_kernel(PassParams p)
                 pk = lane_kmer(ek, nuc2bit(c2));
                 do_probe = valid;
             } else if (st == ST_ALTS) {
-                do_probe = gl < 4;
+                // alt_nucs: the alternative equal to the read's own base IS the trigger k-mer, already
+                // known to be non-solid -> three probes instead of four
+                do_probe = gl < 4 && ((p.flags & 2u) || (uint64_t)gl != (kmer & 3ull));
                 pk = add_nuc(kmer >> 2, (uint64_t)gl, mask);
+                if ((HAS_ONE || HAS_TWO) && !(p.flags & 8u)) {
+                    // the bases the scenarios will look at, fetched once (one coalesced load per group)
+                    const uint32_t wp = i + (uint32_t)gl;
+                    win = group_window((gl < WB && wp < n) ? nuc2bit(ld(wp)) : 0ull);
+                }
             } else if (HAS_ONE && st == ST_SCEN) {
-                const uint32_t e = sub * G + (uint32_t)gl;
-                sc_active = e < 3u * c;
-                sc_s = sc_active ? e / c : 0u;
-                const uint32_t j = sc_active ? e % c : 0u;
+                // get_score look-ahead, staged: look-ahead k-mers [sub, sub+width) of the three
+                // scenarios per round (first the two nearest ones: a wrong scenario almost always dies
+                // there, so its remaining probes are never issued).  Same verdict as probing all c.
+                const uint32_t width = scen_width(sub, c, G, p.flags);
+                const uint32_t e = (uint32_t)gl;
+                sc_active = e < 3u * width;
+                sc_s = sc_active ? e / width : 0u;
+                const uint32_t j = sub + (sc_active ? e % width : 0u);
                 const uint32_t off = 2u - sc_s; // I:2 S:1 D:0 (one.rs:57-63)
                 sc_active = sc_active && !((failmask >> sc_s) & 1u);
                 if (sc_active) {
-                    pk = corr;
-                    for (uint32_t q = 0; q <= j; q++)
-                        pk = add_nuc(pk, nuc2bit(ld(i + off + q)), mask);
+                    if (c + 3u <= (uint32_t)WB && !(p.flags & 8u)) {
+                        pk = ext(corr, win, off, j + 1u);
+                    } else {
+                        pk = corr;
+                        for (uint32_t q = 0; q <= j; q++)
+                            pk = add_nuc(pk, nuc2bit(ld(i + off + q)), mask);
+                    }
                     do_probe = true;
                 }
             } else if (HAS_ONE && st == ST_MORE) {
@@ -497,9 +543,13 @@ __global__ __launch_bounds__(256) void correct_kernel(PassParams p)
                     const uint32_t off = 2u - (uint32_t)gl;
                     const uint32_t rem = n - i;
                     if (rem > c + off + 1u) { // exist/mod.rs:54
-                        pk = corr;
-                        for (uint32_t q = 0; q <= c; q++)
-                            pk = add_nuc(pk, nuc2bit(ld(i + off + q)), mask);
+                        if (c + 3u <= (uint32_t)WB && !(p.flags & 8u)) {
+                            pk = ext(corr, win, off, c + 1u);
+                        } else {
+                            pk = corr;
+                            for (uint32_t q = 0; q <= c; q++)
+                                pk = add_nuc(pk, nuc2bit(ld(i + off + q)), mask);
+                        }
                         do_probe = true;
                     }
                 }
@@ -732,10 +782,10 @@ __global__ __launch_bounds__(256) void correct_kernel(PassParams p)
                     if (b)
                         failmask |= 1u << s;
                 }
-                sub++;
+                sub += scen_width(sub, c, G, p.flags);
                 if (failmask == 7u) {
                     fail = true; // exist/mod.rs:132-134
-                } else if (sub * G >= 3u * c) {
+                } else if (sub >= c) {
                     passmask = 7u & ~failmask;
                     if (__popc(passmask) == 1)
                         apply_s = __ffs(passmask) - 1; // exist/mod.rs:135-137
@@ -939,6 +989,17 @@ __global__ __launch_bounds__(256) void correct_kernel(PassParams p)
                     prev = true;
                     i += 2u - (uint32_t)apply_s;
                     n_fix += (gl == 0);
+                    // The c look-ahead k-mers of the winning scenario ARE the next c scan k-mers and were
+                    // all found solid: the reference's loop would copy these c bases with previous = true
+                    // (mod.rs:99-102).  Accept them without probing again.
+                    if (c > 0u && c + 3u <= (uint32_t)WB && olen + c + 1u <= cap && !(p.flags & 9u)) {
+                        const uint32_t off = 2u - (uint32_t)apply_s;
+                        if ((uint32_t)gl < c)
+                            out[olen + (uint32_t)gl] = ld(i + (uint32_t)gl);
+                        kmer = ext(kmer, win, off, c); // window positions are relative to the trigger
+                        olen += c;
+                        i += c;
+                    }
                     if (i >= n)
                         finish();
                     else
@@ -1108,6 +1169,10 @@ int launch_pass(PassParams p, const brx_method_t &md, int G, hipStream_t s)
     const int method = md.method;
     size_t lds = 0;
     p.max_search = md.max_search;
+    {
+        const char *e = getenv("BRX_TUNE");
+        p.flags = e ? (uint32_t)atoi(e) : 0u;
+    }
     p.g_dim = 0;
     p.g_lds_bytes = 0;
     if (method == BRX_GREEDY) {
