@@ -356,6 +356,10 @@ __global__ __launch_bounds__(256) void correct_kernel(PassParams p)
     // error_len / walk state
     uint32_t elen = 0, ej = 0, npath = 0, gap = 0;
     uint64_t fc = 0, ek = 0, wk = 0;
+    // Brent cycle detector of the graph walk (see ST_WALK)
+    uint64_t tort = 0;
+    uint32_t bpow = 1, blam = 0;
+    bool brent = false;
     TwoCtx tw = {0, 0, 0};
     uint32_t tvalid = 0;
     // greedy state: iteration, path length in bases, alignment offset
@@ -747,6 +751,17 @@ __global__ __launch_bounds__(256) void correct_kernel(PassParams p)
                         npath = 1;
                         wk = corr;
                         st = ST_WALK;
+                        // Graph's viewed_kmer set (graph.rs:47,71-75) only decides WHEN a walk that has
+                        // entered a cycle returns None: the walk is deterministic (unique successor), so
+                        // once a k-mer repeats it can never reach first_correct_kmer any more (every k-mer
+                        // of the cycle was visited before and was not it) -- any cycle detector gives the
+                        // same result.  Brent's needs O(1) state instead of a scan of the visited list.
+                        // Not used when corr == first_correct_kmer (corr is never compared on entry) nor
+                        // for the fixed-length walk of GapSize (a late detection could run past its end).
+                        brent = (mode == MODE_GRAPH) && (corr != fc);
+                        tort = corr;
+                        bpow = 1;
+                        blam = 0;
                     } else if (HAS_GREEDY) {
                         // greedy.rs:135-145: before = kmer2seq(kmer >> 2, k-1); path = [alt]; viewed = {corr}
                         const uint64_t pre = kmer >> 2;
@@ -804,24 +819,43 @@ __global__ __launch_bounds__(256) void correct_kernel(PassParams p)
                     fail = true; // graph.rs:64-67, gap_size.rs:60-68
                 } else {
                     const uint64_t nk = add_nuc(wk, (uint64_t)(__ffs(am) - 1), mask);
-                    bool hit = false; // viewed_kmer.contains(&kmer): graph.rs:71, gap_size.rs:75
-                    for (uint32_t j = gl; j < npath; j += G)
-                        hit |= __hip_atomic_load(path + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nk;
-                    const uint64_t anyhit = (__ballot(hit) >> gshift) & GM;
-                    if (anyhit) {
-                        fail = true;
-                    } else if (npath >= p.maxpath) {
-                        path_overflow();
+                    bool revisit;
+                    if (brent) {
+                        blam++;
+                        revisit = (nk == tort);
+                        if (!revisit && blam == bpow) {
+                            tort = nk;
+                            bpow *= 2u;
+                            blam = 0;
+                        }
                     } else {
-                        if (gl == 0)
+                        bool hit = false; // viewed_kmer.contains(&kmer): graph.rs:71, gap_size.rs:75
+                        const uint32_t stored = npath < p.maxpath ? npath : p.maxpath;
+                        for (uint32_t j = gl; j < stored; j += G)
+                            hit |= __hip_atomic_load(path + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nk;
+                        revisit = ((__ballot(hit) >> gshift) & GM) != 0ull;
+                    }
+                    if (revisit) {
+                        fail = true;
+                    } else if (npath >= p.maxpath && !brent) {
+                        path_overflow(); // the exact scan needs every visited k-mer
+                    } else {
+                        // the visited list doubles as the corrected path; beyond maxpath a (Brent) walk goes
+                        // on unrecorded and only a SUCCESS needs the batch redone with a larger list
+                        if (gl == 0 && npath < p.maxpath)
                             __hip_atomic_store(path + npath, (unsigned long long)nk, __ATOMIC_RELAXED,
                                                __HIP_MEMORY_SCOPE_AGENT);
-                        npath++;
+                        if (npath < 0xfffffff0u)
+                            npath++;
                         wk = nk;
                         if (mode == MODE_GRAPH) {
                             if (nk == fc) { // graph.rs:79-81
-                                apply_path = true;
-                                path_offset = elen + 1u; // graph.rs:84
+                                if (npath > p.maxpath) {
+                                    path_overflow();
+                                } else {
+                                    apply_path = true;
+                                    path_offset = elen + 1u; // graph.rs:84
+                                }
                             }
                         } else if (--gap == 0u) {
                             apply_path = true;
@@ -1112,12 +1146,17 @@ int ensure(void **p, uint64_t *cap, uint64_t need)
     return BRX_OK;
 }
 
-int group_width()
+int group_width(bool reverse_pass = false)
 {
-    // lanes per read; BRX_GROUP overrides (read on every launch so tests can sweep it)
-    const char *e = getenv("BRX_GROUP");
-    const int g = e ? atoi(e) : 16;
-    return (g == 16 || g == 32 || g == 64) ? g : 16;
+    // lanes per read; BRX_GROUP / BRX_GROUP_REV override (read on every launch so tests can sweep them).
+    // The reverse pass of run_correction (src/lib.rs:48-55) sees almost only non-solid k-mers and hardly
+    // ever triggers, so wide groups waste nothing there and save rounds.
+    const char *e = getenv(reverse_pass ? "BRX_GROUP_REV" : "BRX_GROUP");
+    if (!e && reverse_pass)
+        e = getenv("BRX_GROUP");
+    const int dflt = reverse_pass ? 64 : 16; // measured: profiles (ab_correct), +3 % over 16/16
+    const int g = e ? atoi(e) : dflt;
+    return (g == 16 || g == 32 || g == 64) ? g : dflt;
 }
 
 constexpr uint32_t MAX_BLOCKS = 256u * 8u;
@@ -1305,7 +1344,7 @@ int brx_chain_correct_batch_device(brx_chain_t *ch, const uint8_t *d_bases, cons
     for (int m = 0; m < n_methods; m++)
         needs_path |= (ch->methods[m].method == BRX_GRAPH || ch->methods[m].method == BRX_GAP_SIZE ||
                        ch->methods[m].method == BRX_GREEDY);
-    uint32_t maxpath = 512;
+    uint32_t maxpath = 4096; // visited-list capacity per group (1 GiB of scratch at 32768 groups); grows x8 on overflow
 
     for (uint32_t slack = 1, attempt = 0;; attempt++) {
         if (attempt > 12) {
@@ -1354,7 +1393,7 @@ int brx_chain_correct_batch_device(brx_chain_t *ch, const uint8_t *d_bases, cons
                 p.path_k = ch->d_path;
                 p.maxpath = maxpath;
                 BRX_HIP(hipMemsetAsync(ch->d_ctrl + CTL_WORK, 0, 8, s));
-                BRX_TRY(launch_pass(p, ch->methods[m], G, s));
+                BRX_TRY(launch_pass(p, ch->methods[m], dir ? group_width(true) : G, s));
                 cur = ch->d_stage[pp];
                 cur_lens = ch->d_lens[pp];
                 cur_staged = 1;

@@ -12,7 +12,7 @@ from br_amd import _lib, synth
 
 n_reads = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
 rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 5
-variants = [v.split(":") for v in (sys.argv[3:] or ["base:16:0", "legacy:16:7"])]
+variants = [(v.split(":") + ["", ""])[:4] for v in (sys.argv[3:] or ["base:16:0", "legacy:16:7"])]  # name:G:TUNE[:G_REV]
 k, a, read_len = 19, 3, 10000
 cfg = synth.config(genome_len=n_reads * read_len // 50, read_len=read_len)
 stream = torch.cuda.current_stream().cuda_stream
@@ -33,8 +33,9 @@ res = {v[0]: [] for v in variants}
 probes = {}
 _lib.profile_enable(True)
 for r in range(rounds + 1):
-    for name, grp, tune in variants:
+    for name, grp, tune, grev in variants:
         os.environ["BRX_GROUP"], os.environ["BRX_TUNE"] = grp, tune
+        os.environ["BRX_GROUP_REV"] = grev or grp
         _lib.profile_reset()
         chain.correct_batch_device(db.data_ptr(), do.data_ptr(), n_reads, total, d_out.data_ptr(), d_out.numel(), d_oo.data_ptr(), stream)
         ms, n = _lib.profile_get("correct_pass")
