@@ -1,0 +1,150 @@
+"""Full-size (BASELINE.json configs[1]: 1e5 synthetic 10 kb reads, k=19) checks of the HIP path through
+size-independent properties, where the oracle cannot run on everything:
+  - the two build strategies (dense u8 table vs partitioned keys) give the same 16 GiB bitset, and
+    counting in several batches equals counting in one;
+  - reads whose every k-mer is solid come back unchanged (the reference's "no over-correction" asserts);
+  - batch-splitting does not change corrected reads (reads are independent units);
+  - a sample of reads is compared byte for byte with the oracle, using the set exported from HBM.
+"""
+import numpy as np
+import pytest
+
+import br_amd
+from br_amd import _lib, synth
+from br_amd import dist as bd
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+K, ABUNDANCE, N_READS, READ_LEN = 19, 3, 100_000, 10_000
+
+
+@pytest.fixture(scope="module")
+def job():
+    import torch
+    cfg = synth.config(genome_len=N_READS * READ_LEN // 50, read_len=READ_LEN)
+    stream = torch.cuda.current_stream().cuda_stream
+    dg = torch.empty(cfg.genome_len, dtype=torch.uint8, device="cuda")
+    synth.genome_device(cfg, 0, dg.data_ptr(), stream)
+    cap = int(N_READS * READ_LEN * 1.03) + (1 << 20)
+    db = torch.empty(cap, dtype=torch.uint8, device="cuda")
+    do = torch.empty(N_READS + 1, dtype=torch.int64, device="cuda")
+    total = synth.reads_device(cfg, 0, dg.data_ptr(), 0, N_READS, db.data_ptr(), cap, do.data_ptr(), stream)
+    cnt = br_amd.Counter(K, 0, _lib.COUNT_SORTED)
+    cnt.add_batch_device(db.data_ptr(), do.data_ptr(), N_READS, total, stream)
+    solid = cnt.finish(ABUNDANCE, stream)
+    del cnt
+    return {"cfg": cfg, "bases": db, "offsets": do, "total": total, "solid": solid, "stream": stream, "genome": dg}
+
+
+def _bits_tensor(s):
+    import torch
+    ptr, n = s.device_bits()
+    return bd.device_view(ptr, n).view(torch.int64)
+
+
+def test_build_strategies_and_batching_agree(job):
+    import torch
+    stream = job["stream"]
+    ref = _bits_tensor(job["solid"])
+    n_solid = job["solid"].popcount()
+    assert 15_000_000 < n_solid < 40_000_000          # ~ genome size (20 Mbp) + a few solid error k-mers
+
+    # dense: the reference's own data structure (2^37-byte u8 table)
+    cnt = br_amd.Counter(K, 0, _lib.COUNT_DENSE)
+    cnt.add_batch_device(job["bases"].data_ptr(), job["offsets"].data_ptr(), N_READS, job["total"], stream)
+    dense = cnt.finish(ABUNDANCE, stream)
+    del cnt
+    torch.cuda.synchronize()
+    assert dense.popcount() == n_solid
+    assert torch.equal(_bits_tensor(dense), ref)
+    del dense
+
+    # partitioned, three unequal batches (exercises the per-bucket merge of batches)
+    off_h = job["offsets"].cpu()
+    cuts = [0, 17_000, 60_001, N_READS]
+    cnt = br_amd.Counter(K, 0, _lib.COUNT_SORTED)
+    keep = []
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        sub_off = (job["offsets"][a:b + 1]).contiguous()
+        keep.append(sub_off)
+        nb = int(off_h[b] - off_h[a])
+        cnt.add_batch_device(job["bases"].data_ptr(), sub_off.data_ptr(), b - a, nb, stream)
+    merged = cnt.finish(ABUNDANCE, stream)
+    torch.cuda.synchronize()
+    assert torch.equal(_bits_tensor(merged), ref)
+
+
+def test_all_solid_reads_come_back_unchanged(job):
+    """abundance 0 makes every k-mer of the reads solid: nothing can trigger, the forward scan is the
+    identity (the `assert_eq!(refe, corrector.correct(refe))` half of every reference unit test)."""
+    import torch
+    stream = job["stream"]
+    n = 30_000
+    off = job["offsets"][:n + 1].contiguous()
+    nb = int(off[-1].item())
+    cnt = br_amd.Counter(K, 0, _lib.COUNT_SORTED)
+    cnt.add_batch_device(job["bases"].data_ptr(), off.data_ptr(), n, nb, stream)
+    every = cnt.finish(0, stream)
+    del cnt
+    d_out = torch.empty(nb + (1 << 20), dtype=torch.uint8, device="cuda")
+    d_oo = torch.empty(n + 1, dtype=torch.int64, device="cuda")
+    for method in ("one", "graph", "gap_size", "two"):
+        chain = br_amd.Chain(every, [(method, 5, 7)], two_side=True)
+        tot = chain.correct_batch_device(job["bases"].data_ptr(), off.data_ptr(), n, nb, d_out.data_ptr(), d_out.numel(),
+                                         d_oo.data_ptr(), stream)
+        assert tot == nb
+        assert torch.equal(d_oo, off)
+        assert torch.equal(d_out[:nb], job["bases"][:nb])
+        assert chain.last_stats()["triggers"] == 0
+
+
+def test_batch_split_invariance(job):
+    """reads are independent units: correcting [A|B] in one call == correcting A and B separately."""
+    import torch
+    stream = job["stream"]
+    n = 40_000
+    off_h = job["offsets"][:n + 1].cpu()
+    nb = int(off_h[-1])
+    chain = br_amd.Chain(job["solid"], [("one", 5, 7)], two_side=False)
+    out_all = torch.empty(int(nb * 1.05) + (1 << 20), dtype=torch.uint8, device="cuda")
+    oo_all = torch.empty(n + 1, dtype=torch.int64, device="cuda")
+    off = job["offsets"][:n + 1].contiguous()
+    tot_all = chain.correct_batch_device(job["bases"].data_ptr(), off.data_ptr(), n, nb, out_all.data_ptr(), out_all.numel(),
+                                         oo_all.data_ptr(), stream)
+    pieces = []
+    for a, b in ((0, 12_345), (12_345, n)):
+        sub = job["offsets"][a:b + 1].contiguous()
+        snb = int(off_h[b] - off_h[a])
+        o = torch.empty(int(snb * 1.05) + (1 << 20), dtype=torch.uint8, device="cuda")
+        oo = torch.empty(b - a + 1, dtype=torch.int64, device="cuda")
+        t = chain.correct_batch_device(job["bases"].data_ptr(), sub.data_ptr(), b - a, snb, o.data_ptr(), o.numel(),
+                                       oo.data_ptr(), stream)
+        pieces.append(o[:t])
+    assert torch.equal(torch.cat(pieces), out_all[:tot_all])
+
+
+def test_sample_of_reads_matches_oracle(job):
+    """byte parity on a sample, with the very set the GPU built (exported from HBM, 16 GiB)."""
+    import torch
+    stream = job["stream"]
+    bits = job["solid"].export_bits()
+    osolid = O.Solid.wrap(K, bits)
+    d_out = torch.empty(int(job["total"] * 1.05) + (1 << 20), dtype=torch.uint8, device="cuda")
+    d_oo = torch.empty(N_READS + 1, dtype=torch.int64, device="cuda")
+    rng = np.random.default_rng(5)
+    sample = sorted(set(rng.integers(0, N_READS, size=120).tolist()) | {0, N_READS - 1})
+    off_h = job["offsets"].cpu().numpy()
+    for methods in (["one"], ["one", "graph"]):
+        chain = br_amd.Chain(job["solid"], [(m, 5, 7) for m in methods], two_side=False)
+        tot = chain.correct_batch_device(job["bases"].data_ptr(), job["offsets"].data_ptr(), N_READS, job["total"],
+                                         d_out.data_ptr(), d_out.numel(), d_oo.data_ptr(), stream)
+        oo_h = d_oo.cpu().numpy()
+        assert int(oo_h[-1]) == tot
+        om = O.build_methods(osolid, methods, 5, 7)
+        for r in sample:
+            src = job["bases"][int(off_h[r]):int(off_h[r + 1])].cpu().numpy().tobytes()
+            got = d_out[int(oo_h[r]):int(oo_h[r + 1])].cpu().numpy().tobytes()
+            assert got == O.correct_record(om, src, False), (methods, r)
+        st = chain.last_stats()
+        assert st["fixes"] > 10_000_000
