@@ -1,0 +1,172 @@
+"""Command-line surface of `br` (src/cli.rs:19-76, 172-185; dispatch src/main.rs:17-58), over the HIP path.
+
+    python -m br_amd -i reads.fa -o corr.fa [-s] [-c one -c graph ...] [-C 5] [-M 7] \
+        fasta -i reads.fa -k 19 -a 3                       # count -> threshold -> correct (src/main.rs:72-85)
+        solid -i set.solid -f solid                        # load a pcon .solid set     (src/main.rs:117-120)
+        solid -i reads.fa -f fasta -k 19                   # presence-only set          (src/set/pcon.rs:47-112)
+
+Same flags, defaults and quirks as the reference: `-s/--two-side` DISABLES the reverse pass
+(src/lib.rs:48,110); `fasta -k` is forced odd (src/cli.rs:277-279); without `-a` an abundance method
+sub-command is needed (src/main.rs:95-110).  `first-minimum` is implemented from pcon's published
+algorithm (first index where the count spectrum rises; unpinned by the reference's tests);
+`rarefaction` / `percent-most` / `percent-least`, the `count` sub-command (pcon count files) and
+`large-kmer` (hash set, k <= 32) are rows N2-N4 of SURVEY 8(f) and fail loudly here.  `-t` (rayon
+pool size) is accepted and ignored: the GPU is the pool.
+"""
+from __future__ import annotations
+
+import argparse
+import bz2
+import gzip
+import io
+import lzma
+import sys
+from typing import BinaryIO, List, Optional
+
+from . import _lib, fasta
+from .correct import build_methods
+from .driver import run_correction
+from .set import Counter, Pcon
+
+METHOD_NAMES = ["one", "two", "graph", "greedy", "gap-size"]  # clap ValueEnum kebab-case of CorrectionMethod
+
+
+def open_input(path: str) -> BinaryIO:
+    """niffler::get_reader: sniff gz / bz2 / xz by magic bytes (src/cli.rs:209,269,404,415)."""
+    raw = open(path, "rb")
+    head = raw.peek(6)[:6] if hasattr(raw, "peek") else b""
+    if head[:2] == b"\x1f\x8b":
+        return gzip.open(raw, "rb")
+    if head[:3] == b"BZh":
+        return bz2.open(raw, "rb")
+    if head[:6] == b"\xfd7zXZ\x00":
+        return lzma.open(raw, "rb")
+    return raw
+
+
+def parser() -> argparse.ArgumentParser:
+    p = argparse.ArgumentParser(prog="br", description="Br: Brutal rewrite a simple long read corrector based on kmer "
+                                                       "spectrum methode (MI355X-native hot path)")
+    # clap derive, Option<Vec<T>>: ONE value per occurrence, repeat the flag for more (-i a -i b)
+    p.add_argument("-i", "--inputs", action="append", default=None, help="Path to inputs, default read stdin")
+    p.add_argument("-o", "--outputs", action="append", default=None, help="Path to output, default stdout")
+    p.add_argument("-s", "--two-side", action="store_true", help="Correct in two side (sic: disables the reverse pass)")
+    p.add_argument("-c", "--corrections", action="append", choices=METHOD_NAMES, default=None,
+                   help="Correction method")
+    p.add_argument("-C", "--confirm", type=int, default=None, help="Number of kmer required to validate correction")
+    p.add_argument("-M", "--max-search", type=int, default=None, help="Number of base we use to try correct error")
+    p.add_argument("-b", "--record_buffer", type=int, default=None, help="Number of sequence record load in buffer")
+    p.add_argument("-t", "--threads", type=int, default=None, help="accepted for compatibility, ignored")
+    p.add_argument("-q", "--quiet", action="store_true")
+    p.add_argument("-v", "--verbosity", action="count", default=0)
+    p.add_argument("-T", "--timestamp", default=None)
+    p.add_argument("--device", type=int, default=0, help="GPU index (not in the reference)")
+    sub = p.add_subparsers(dest="subcommand", required=True)
+
+    def abundance_methods(sp):
+        ssub = sp.add_subparsers(dest="abundance_selection")
+        ssub.add_parser("first-minimum")
+        for name in ("rarefaction", "percent-most", "percent-least"):
+            ssub.add_parser(name).add_argument("percent", type=float)
+
+    c = sub.add_parser("count", help="With Count")
+    c.add_argument("-i", "--inputs", dest="sub_inputs", required=True)
+    c.add_argument("-a", "--abundance", type=int, default=None)
+    abundance_methods(c)
+    f = sub.add_parser("fasta", help="With Fasta")
+    f.add_argument("-i", "--inputs", dest="sub_inputs", action="append", required=True)
+    f.add_argument("-k", "--kmer-size", type=int, required=True)
+    f.add_argument("-a", "--abundance", type=int, default=None)
+    abundance_methods(f)
+    s = sub.add_parser("solid", help="With Solid")
+    s.add_argument("-i", "--input", dest="sub_input", required=True)
+    s.add_argument("-f", "--format", choices=["solid", "fasta"], required=True)
+    s.add_argument("-k", "--kmer-size", type=int, default=None)
+    lk = sub.add_parser("large-kmer", help="Large Kmer mode")
+    lk.add_argument("-i", "--input", dest="sub_input", required=True)
+    lk.add_argument("-f", "--format", choices=["fasta"], required=True)
+    lk.add_argument("-k", "--kmer-size", type=int, required=True)
+    return p
+
+
+def fasta_kmer_size(k: int) -> int:
+    """Fasta::kmer_size, src/cli.rs:277-279: even k becomes k-1 (asserted 14 -> 13 at src/cli.rs:459)."""
+    return k - ((~(k & 1)) & 1)
+
+
+def first_minimum(spectrum) -> Optional[int]:
+    """pcon::spectrum ThresholdMethod::FirstMinimum: first index i with spectrum[i+1] > spectrum[i]."""
+    for i in range(len(spectrum) - 1):
+        if int(spectrum[i + 1]) > int(spectrum[i]):
+            return i
+    return None
+
+
+def _records(paths: List[str]):
+    for path in paths:
+        with open_input(path) as f:
+            for _, _, seq in fasta.read_records(f):
+                yield seq
+
+
+def build_set(args) -> Pcon:
+    dev = args.device
+    if args.subcommand == "fasta":
+        k = fasta_kmer_size(args.kmer_size)
+        if args.abundance is not None:
+            return Pcon.from_count(_records(args.sub_inputs), k, args.abundance, dev)
+        if args.abundance_selection == "first-minimum":
+            cnt = Counter(k, dev, _lib.COUNT_DENSE)  # the spectrum needs the u8 table
+            chunk = []
+            for seq in _records(args.sub_inputs):
+                chunk.append(seq)
+                if len(chunk) == 8192:
+                    cnt.add_reads(chunk)
+                    chunk = []
+            if chunk:
+                cnt.add_reads(chunk)
+            thr = first_minimum(cnt.spectrum())
+            if thr is None:
+                raise SystemExit("Error: Can't compute minimal abundance")          # error.rs ComputeAbundanceThreshold
+            return cnt.finish(thr)
+        if args.abundance_selection is None:
+            raise SystemExit("Error: You must provide an abundance method or an abundance threshold")  # main.rs:109
+        raise SystemExit(f"abundance method {args.abundance_selection!r} is not implemented on the HIP path "
+                         "(pcon::spectrum formula unpinned, SURVEY 8(f) N2); pass -a N")
+    if args.subcommand == "solid":
+        if args.format == "solid":
+            with open_input(args.sub_input) as f:
+                return Pcon.from_pcon_solid(f.read(), dev)
+        if args.kmer_size is None:
+            raise SystemExit("Error: Solid input fasta require kmer size")            # error.rs SolidRequireKmerSize
+        return Pcon.from_fasta(_records([args.sub_input]), args.kmer_size, dev)
+    if args.subcommand == "count":
+        raise SystemExit("the pcon count-file format is not implemented on the HIP path (unpinned, SURVEY 8(f) N3)")
+    raise SystemExit("large-kmer (hash set) mode is not implemented on the HIP path (SURVEY 8(f) N4)")
+
+
+def main(argv: Optional[List[str]] = None) -> int:
+    args = parser().parse_args(argv)
+    kmer_set = build_set(args)
+    names = args.corrections or METHOD_NAMES                          # src/cli.rs:121-131: all five by default
+    confirm = 5 if args.confirm is None else args.confirm            # src/cli.rs:135-137
+    max_search = 7 if args.max_search is None else args.max_search   # src/cli.rs:140-142
+    methods = build_methods(names, kmer_set, confirm, max_search)
+    inputs = [open_input(p) for p in args.inputs] if args.inputs else [sys.stdin.buffer]
+    outputs = [open(p, "wb") for p in args.outputs] if args.outputs else [io.BufferedWriter(sys.stdout.buffer)]
+    try:
+        run_correction(inputs, outputs, methods, args.two_side, args.record_buffer or 8192)
+    finally:
+        for f in outputs:
+            f.flush()
+        for f in inputs + outputs:
+            if f not in (sys.stdin.buffer,):
+                try:
+                    f.close()
+                except Exception:
+                    pass
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -120,6 +120,26 @@ __global__ __launch_bounds__(256) void clamp_kernel(uint4 *__restrict__ counts, 
     }
 }
 
+// 256-bin histogram of the u8 counts (pcon::spectrum::Spectrum::from_count, src/main.rs:93)
+__global__ __launch_bounds__(256) void spectrum_kernel(const uint32_t *__restrict__ counts, uint64_t nwords,
+                                                       unsigned long long *__restrict__ hist)
+{
+    __shared__ unsigned int sh[256];
+    sh[threadIdx.x] = 0;
+    __syncthreads();
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nwords; i += stride) {
+        const uint32_t w = counts[i];
+        atomicAdd(&sh[w & 0xffu], 1u);
+        atomicAdd(&sh[(w >> 8) & 0xffu], 1u);
+        atomicAdd(&sh[(w >> 16) & 0xffu], 1u);
+        atomicAdd(&sh[w >> 24], 1u);
+    }
+    __syncthreads();
+    if (sh[threadIdx.x])
+        atomicAdd(&hist[threadIdx.x], (unsigned long long)sh[threadIdx.x]);
+}
+
 __global__ void get_kernel(const uint32_t *__restrict__ bits, const uint64_t *__restrict__ kmers, uint32_t n, int k,
                            uint8_t *__restrict__ out)
 {
@@ -643,6 +663,38 @@ int brx_set_count_finish(brx_counter_t *c, uint8_t abundance, void *stream, brx_
         return st;
     }
     *out = set;
+    return BRX_OK;
+}
+
+int brx_counter_spectrum(brx_counter_t *c, uint64_t *hist256, void *stream)
+{
+    if (!c || !hist256)
+        return BRX_ERR_ARG;
+    if (c->strategy != BRX_COUNT_DENSE) {
+        set_error("spectrum needs the dense count strategy");
+        return BRX_ERR_UNSUPPORTED;
+    }
+    BRX_TRY(use_device(c->device));
+    hipStream_t s = (hipStream_t)stream;
+    unsigned long long *d_h = nullptr;
+    BRX_HIP(hipMalloc((void **)&d_h, 256 * 8));
+    hipError_t e = hipMemsetAsync(d_h, 0, 256 * 8, s);
+    const uint64_t nbytes = set_nbits(c->k); // real entries (the table may be padded to 32 B)
+    if (e == hipSuccess) {
+        KernelTimer t("spectrum", s);
+        // padded tail (k <= 2) would add zeros: count whole words of real entries only
+        spectrum_kernel<<<grid_for(nbytes / 4 ? nbytes / 4 : 1, 256 * 16, 2048), 256, 0, s>>>(c->d_counts, nbytes / 4 ? nbytes / 4 : 1, d_h);
+        e = hipMemcpyAsync(hist256, d_h, 256 * 8, hipMemcpyDeviceToHost, s);
+    }
+    if (e == hipSuccess)
+        e = hipStreamSynchronize(s);
+    (void)hipFree(d_h);
+    if (e != hipSuccess) {
+        set_error("spectrum: %s", hipGetErrorString(e));
+        return BRX_ERR_HIP;
+    }
+    if (nbytes < 4) // k = 1: 2 entries in a padded word; remove the 2 padding zeros of the first word
+        hist256[0] -= 4 - nbytes;
     return BRX_OK;
 }
 

@@ -203,6 +203,12 @@ class Counter:
         _lib.check(_lib.lib().brx_counter_device_counts(self._h, C.byref(p), C.byref(n)))
         return p.value, n.value
 
+    def spectrum(self, stream: Optional[int] = None) -> np.ndarray:
+        """pcon::spectrum::Spectrum::from_count: uint64[256] histogram of the counts (dense strategy)."""
+        h = np.zeros(256, dtype=np.uint64)
+        _lib.check(_lib.lib().brx_counter_spectrum(self._h, h.ctypes.data_as(C.POINTER(C.c_uint64)), stream))
+        return h
+
     def l1_view(self) -> Tuple[int, int, int, int]:
         """(d_keys, d_l1off, n_buckets, n_keys) of the single counted batch (partitioned strategy)."""
         pk, po, nb, nk = C.c_void_p(), C.c_void_p(), C.c_uint32(0), C.c_uint64(0)

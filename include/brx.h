@@ -122,6 +122,9 @@ int brx_set_count_finish(brx_counter_t *c, uint8_t abundance, void *stream, brx_
 int brx_set_count_finish_into(brx_counter_t *c, uint8_t abundance, void *stream, brx_set_t *dst);
 /* forget everything counted so far (Counter::new without re-allocating; async on `stream`)   */
 int brx_counter_reset(brx_counter_t *c, void *stream);
+/* dense strategy only: 256-bin histogram of the counts = pcon::spectrum::Spectrum::from_count
+ * (src/main.rs:93); hist256[v] = number of canonical k-mers seen exactly v times (255 = 255 or more) */
+int brx_counter_spectrum(brx_counter_t *c, uint64_t *hist256, void *stream);
 /* dense strategy only: device view of the u8 table, for the RCCL reduction of SURVEY 8(e)   */
 int brx_counter_device_counts(brx_counter_t *c, void **d_counts, uint64_t *n_bytes);
 /* clamp every count to min(count, cap) in place (the exact-sum trick before an u8 all-reduce) */

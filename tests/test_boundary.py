@@ -92,3 +92,25 @@ def test_synth_host_deterministic_and_error_rates():
     for i in range(20):
         r = b0[int(o0[i]):int(o0[i + 1])].tobytes()
         assert len(r) == 500 and (r in gs or r.translate(comp)[::-1] in gs)
+
+
+def test_cli_surface_matches_reference():
+    """flags/defaults/quirks of src/cli.rs, without touching the GPU."""
+    from br_amd import cli
+    p = cli.parser()
+    a = p.parse_args(["-i", "a.fa", "-i", "b.fa", "-o", "o.fa", "-s", "-c", "one", "-c", "gap-size", "-C", "3", "-M", "9",
+                      "-t", "4", "fasta", "-i", "r.fa", "-k", "14", "-a", "2"])
+    assert a.inputs == ["a.fa", "b.fa"] and a.outputs == ["o.fa"] and a.two_side
+    assert a.corrections == ["one", "gap-size"] and a.confirm == 3 and a.max_search == 9
+    assert a.subcommand == "fasta" and a.sub_inputs == ["r.fa"] and a.abundance == 2
+    assert cli.fasta_kmer_size(a.kmer_size) == 13          # src/cli.rs:459
+    assert cli.fasta_kmer_size(13) == 13
+    a = p.parse_args(["fasta", "-i", "r.fa", "-k", "11", "first-minimum"])
+    assert a.inputs is None and a.corrections is None and a.abundance is None
+    assert a.abundance_selection == "first-minimum"
+    a = p.parse_args(["solid", "-i", "x.solid", "-f", "solid"])
+    assert a.subcommand == "solid" and a.format == "solid" and a.kmer_size is None
+    # spectrum of raw.fasta at k=11 (SURVEY 8(f) N2): first rise at index 6 -> 7
+    assert cli.first_minimum([1436018, 442564, 95498, 19526, 4458, 1221, 460, 494, 100]) == 6
+    assert cli.first_minimum([5, 4, 3]) is None
+    assert cli.METHOD_NAMES == ["one", "two", "graph", "greedy", "gap-size"]   # default order, src/cli.rs:121-131

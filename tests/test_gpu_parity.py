@@ -484,3 +484,39 @@ def test_build_partitioned_over_rccl_single_rank(raw_reads):
             assert solid.to_solid_bytes() == ref.to_bytes()
     finally:
         dist.destroy_process_group()
+
+
+def test_cli_reference_integration_commands(tmp_path, golden_dir, raw_reads, solid_fixture_bytes):
+    """the reference's integration tests (tests/br.rs:9-59) as CLI invocations of the HIP path: exit 0,
+    and -- which the reference never checks -- output equal to the oracle's."""
+    from br_amd import cli, fasta
+    raw = os.path.join(golden_dir, "raw.fasta")
+    out1, out2 = str(tmp_path / "corr1.fasta"), str(tmp_path / "corr2.fasta")
+    # tests/br.rs:35-59: br -i raw.fasta -o corr.fasta solid -i raw.k11.a2.solid -f solid   (all five methods)
+    assert cli.main(["-i", raw, "-o", out1, "solid", "-i", os.path.join(golden_dir, "raw.k11.a2.solid"), "-f", "solid"]) == 0
+    os_ = O.Solid.from_bytes(solid_fixture_bytes)
+    om = O.build_methods(os_, ["one", "two", "graph", "greedy", "gap_size"], 5, 7)
+    got = list(fasta.read_records(open(out1, "rb")))
+    assert len(got) == 206
+    for (_, _, seq), r in zip(got[:40], raw_reads[:40]):
+        assert seq == O.correct_record(om, r, False)
+    # tests/br.rs:9-33: br -i raw.fasta -o corr.fasta fasta -i raw.fasta -k 11 first-minimum
+    assert cli.main(["-i", raw, "-o", out2, "-c", "one", "fasta", "-i", raw, "-k", "11", "first-minimum"]) == 0
+    counts = O.count_reads(11, raw_reads)
+    spec = np.bincount(counts, minlength=256)
+    thr = cli.first_minimum(spec)
+    assert thr == 6
+    ref = O.Solid.from_count(11, counts, thr)
+    om = O.build_methods(ref, ["one"], 5, 7)
+    got = list(fasta.read_records(open(out2, "rb")))
+    for (_, _, seq), r in zip(got[:60], raw_reads[:60]):
+        assert seq == O.correct_record(om, r, False)
+
+
+def test_spectrum_matches_oracle(raw_reads):
+    cnt = br_amd.Counter(11, 0, _lib.COUNT_DENSE)
+    cnt.add_reads(raw_reads)
+    spec = cnt.spectrum()
+    exp = np.bincount(O.count_reads(11, raw_reads), minlength=256)
+    assert np.array_equal(spec.astype(np.int64), exp.astype(np.int64))
+    assert spec[:8].tolist() == [1436018, 442564, 95498, 19526, 4458, 1221, 460, 494]   # SURVEY 8(f) N2
