@@ -1156,7 +1156,7 @@ int group_width(bool reverse_pass = false)
         e = getenv("BRX_GROUP");
     const int dflt = reverse_pass ? 64 : 16; // measured: profiles (ab_correct), +3 % over 16/16
     const int g = e ? atoi(e) : dflt;
-    return (g == 16 || g == 32 || g == 64) ? g : dflt;
+    return (g == 8 || g == 16 || g == 32 || g == 64) ? g : dflt;
 }
 
 constexpr uint32_t MAX_BLOCKS = 256u * 8u;
@@ -1181,7 +1181,9 @@ int launch_method(const PassParams &p, int G, uint32_t blocks, size_t lds, hipSt
                        : G == 32 ? (const void *)correct_kernel<32, M> : (const void *)correct_kernel<64, M>;
         BRX_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
-    if (G == 16)
+    if (G == 8 && M == BRX_ONE)
+        correct_kernel<8, BRX_ONE><<<blocks, 256, lds, s>>>(p);
+    else if (G <= 16)
         correct_kernel<16, M><<<blocks, 256, lds, s>>>(p);
     else if (G == 32)
         correct_kernel<32, M><<<blocks, 256, lds, s>>>(p);
@@ -1352,7 +1354,7 @@ int brx_chain_correct_batch_device(brx_chain_t *ch, const uint8_t *d_bases, cons
             return BRX_ERR_OVERFLOW;
         }
         if (needs_path) {
-            const uint64_t n_groups = (uint64_t)MAX_BLOCKS * 16u; // upper bound over every group width
+            const uint64_t n_groups = (uint64_t)MAX_BLOCKS * 16u; // upper bound over every group width used by walking methods
             BRX_TRY(ensure((void **)&ch->d_path, &ch->path_bytes, n_groups * maxpath * 8ull));
         }
         const uint64_t stage_need = total_bases + (total_bases >> 2) * slack + 64ull * ((uint64_t)n_reads + 1) + 64;

@@ -444,7 +444,7 @@ constexpr uint32_t CNT_WORDS = F_SIZE / 2;  // u16 counters, 2 per word: hash h 
 constexpr uint32_t BIT_WORDS = F_SIZE / 32; // 128
 constexpr uint32_t CHUNK_MAX = 65000;       // keys counted between two clamps (the u16 halves must not carry)
 
-constexpr uint32_t STAGE_KEYS = 2048;       // keys of a group of buckets staged in LDS per wave
+constexpr uint32_t STAGE_KEYS = 704;        // keys of a group of buckets staged in LDS per wave (4 blocks per CU)
 
 __global__ __launch_bounds__(64 * P3_WAVES) void final_count_kernel(const uint16_t *__restrict__ keys,
                                                                      const uint64_t *__restrict__ off, uint64_t n_buckets,

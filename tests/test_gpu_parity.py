@@ -184,7 +184,7 @@ def test_unit_vectors_on_gpu(unit_vectors):
     assert ran >= 80
 
 
-@pytest.mark.parametrize("group", ["16", "32", "64"])
+@pytest.mark.parametrize("group", ["8", "16", "32", "64"])
 def test_one_raw_fasta_fixture_set(raw_reads, solid_fixture_bytes, group, monkeypatch):
     """the reference's `solid` integration config (tests/br.rs:35-59): raw.fasta corrected with
     raw.k11.a2.solid, method One, c=5, forward + reverse pass; byte-identical to the oracle."""
