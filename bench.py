@@ -230,7 +230,7 @@ def cpu_baseline(args, cfg, gs, k, n_reads):
     from oracle import oracle as O
 
     cores = min(os.cpu_count() or 1, 16)
-    S = args.cpu_reads or min(n_reads, 1024 * cores)
+    S = args.cpu_reads or min(n_reads, 4096 * cores)   # ~10-20 s of CPU work on 16 threads
     bits = gs.export_bits()                       # 2^(2k-4) bytes, D2H once
     g = synth.genome_host(cfg)
     bases, offs = synth.reads_host(cfg, g, 0, S)
