@@ -65,10 +65,6 @@ def main():
 
     torch.cuda.set_device(local_rank)
     dev = local_rank
-    if world > 1 or args.force_exchange:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     stream = torch.cuda.current_stream().cuda_stream
 
     k, a = args.k, args.abundance
@@ -92,11 +88,16 @@ def main():
     gs = br_amd.Pcon.new(k, dev)
     chain = br_amd.Chain(gs, [("one", args.confirm, 7)], two_side=False)
 
+    # The process group is created AFTER the big HBM allocations above (measured: buffers allocated
+    # after RCCL's communicator exists stream at a fraction of the bandwidth on this stack).
+    if world > 1 or args.force_exchange:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     from br_amd import dist as brx_dist
     multi = world > 1 or args.force_exchange
     exchanger = brx_dist.SetExchange(world, rank) if multi else None
     partitioned = multi and (args.strategy == "sorted" or (args.strategy == "auto" and k >= 15))
-    owned = br_amd.Counter(k, dev, _lib.COUNT_SORTED) if partitioned else None
 
     phase_ms = {"build": 0.0, "correct": 0.0}
 
@@ -105,7 +106,7 @@ def main():
         counter.reset(stream)
         counter.add_batch_device(d_bases.data_ptr(), d_off.data_ptr(), n_reads, total, stream)
         if exchanger is not None and partitioned:
-            exchanger.build_partitioned(counter, owned, gs, a, stream)   # keys to their owner, solid set back
+            exchanger.build_partitioned(counter, gs, a, stream)   # keys to their owner, solid set back
         else:
             if exchanger is not None:
                 exchanger.reduce_counts(counter, a, stream)              # dense: u8 all-reduce
@@ -152,6 +153,16 @@ def main():
     prof = _lib.profile_all()
     stats = chain.last_stats()
     solid_bits = gs.popcount()
+    # cheap self-checks of the job (a wrong set shows up here long before anyone diffs FASTA files):
+    # every rank must hold the same set, and roughly one solid k-mer per genome position and strand-pair
+    checks = {"solid_per_genome_base": round(solid_bits / genome_len, 3)}
+    if world > 1:
+        lo = torch.tensor([solid_bits], dtype=torch.int64, device="cuda")
+        hi = lo.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        checks["set_popcount_identical_across_ranks"] = bool(lo.item() == hi.item())
+    checks["plausible"] = bool(0.9 < solid_bits / genome_len < 1.3 and stats["fixes"] > 0.01 * total)
 
     # ---- roofline of the dominant kernel ---------------------------------------------------------
     n_table = 1 << (2 * k - 1)
@@ -211,6 +222,7 @@ def main():
                         for n, v in prof.items() if v["launches"]},
             "correct_stats": {**{k_: int(v) for k_, v in stats.items()}, "out_bases": int(out_total),
                               "solid_kmers": int(solid_bits)},
+            "checks": checks,
             "roofline": roofline,
             "cpu_baseline": cpu,
         }

@@ -171,36 +171,99 @@ __global__ __launch_bounds__(256) void popcount_kernel(const uint32_t *__restric
         atomicAdd(total, acc);
 }
 
-// compacts the set bits of words [w0, w0+nw) into a list of absolute bit indices (any order)
+// compacts the set bits of words [w0, w0+nw) into a list of absolute bit indices (any order).
+// The set is sparse (k=19: 2e7 bits in 4e9 words): a wave streams 64 x 16 bytes per iteration and only
+// enters the compaction when its ballot says some lane holds a non-zero word.  Found indices are
+// collected in an LDS buffer per workgroup and flushed with ONE global atomic per ~2000 entries
+// (a single global counter hit once per wave serialises at ~3.5 ns per atomic).
+constexpr uint32_t EXTRACT_BUF = 2048;
+
+__device__ __forceinline__ void extract_flush(uint64_t *lbuf, uint32_t *lcount, unsigned long long *counter, uint64_t *out,
+                                              uint64_t cap, unsigned long long *sh_base)
+{
+    __syncthreads();
+    const uint32_t n = *lcount < EXTRACT_BUF + 1024u ? *lcount : EXTRACT_BUF + 1024u;
+    if (threadIdx.x == 0)
+        *sh_base = n ? atomicAdd(counter, (unsigned long long)n) : 0ull;
+    __syncthreads();
+    const unsigned long long base = *sh_base;
+    for (uint32_t j = threadIdx.x; j < n; j += blockDim.x)
+        if (base + j < cap)
+            out[base + j] = lbuf[j];
+    __syncthreads();
+    if (threadIdx.x == 0)
+        *lcount = 0;
+    __syncthreads();
+}
+
 __global__ __launch_bounds__(256) void extract_kernel(const uint32_t *__restrict__ bits, uint64_t w0, uint64_t nw,
                                                       unsigned long long *__restrict__ counter, uint64_t *__restrict__ out,
                                                       uint64_t cap)
 {
+    // one iteration of the block adds at most 256 lanes x 128 bits... in practice a few; the buffer has
+    // 1024 entries of head-room above the flush threshold and a dense iteration flushes first
+    __shared__ uint64_t lbuf[EXTRACT_BUF + 1024];
+    __shared__ uint32_t lcount;
+    __shared__ unsigned long long sh_base;
+    if (threadIdx.x == 0)
+        lcount = 0;
+    __syncthreads();
+    const uint64_t nq = nw / 4; // whole uint4 groups; the tail (< 4 words) is handled by block 0 below
+    const uint4 *q = reinterpret_cast<const uint4 *>(bits + w0);
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    const int lane = threadIdx.x & 63;
-    for (uint64_t i0 = (uint64_t)blockIdx.x * blockDim.x; i0 < nw; i0 += stride) {
+    for (uint64_t i0 = (uint64_t)blockIdx.x * blockDim.x; i0 < nq; i0 += stride) { // block-uniform trip count
         const uint64_t i = i0 + threadIdx.x;
-        uint32_t w = i < nw ? bits[w0 + i] : 0u;
-        const uint32_t n = __popc(w);
-        // wave-inclusive scan of n, one atomic per wave
-        uint32_t incl = n;
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t t = __shfl_up(incl, d);
-            if (lane >= d)
-                incl += t;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (i < nq)
+            v = q[i];
+        const uint32_t n = __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w);
+        const bool any_in_block = __syncthreads_or(n != 0);
+        if (!any_in_block)
+            continue;
+        // dense data: make room first (n <= 128 per lane, so one iteration can add up to 32768 entries;
+        // handle that by letting lanes with many bits write straight to global memory)
+        if (n) {
+            if (n > 4u) {
+                const unsigned long long base = atomicAdd(counter, (unsigned long long)n);
+                unsigned long long pos = base;
+                uint32_t w[4] = {v.x, v.y, v.z, v.w};
+                for (int c = 0; c < 4; c++) {
+                    uint32_t x = w[c];
+                    while (x) {
+                        const int b = __ffs(x) - 1;
+                        x &= x - 1u;
+                        if (pos < cap)
+                            out[pos] = ((w0 + 4 * i + c) << 5) + (uint64_t)b;
+                        pos++;
+                    }
+                }
+            } else {
+                uint32_t slot = atomicAdd(&lcount, n); // <= 4 per lane, <= 1024 per iteration
+                uint32_t w[4] = {v.x, v.y, v.z, v.w};
+                for (int c = 0; c < 4; c++) {
+                    uint32_t x = w[c];
+                    while (x) {
+                        const int b = __ffs(x) - 1;
+                        x &= x - 1u;
+                        lbuf[slot++] = ((w0 + 4 * i + c) << 5) + (uint64_t)b;
+                    }
+                }
+            }
         }
-        const uint32_t wave_total = __shfl(incl, 63);
-        unsigned long long base = 0;
-        if (lane == 63 && wave_total)
-            base = atomicAdd(counter, (unsigned long long)wave_total);
-        base = __shfl(base, 63);
-        unsigned long long pos = base + incl - n;
-        while (w) {
-            const int b = __ffs(w) - 1;
-            w &= w - 1u;
+        __syncthreads();
+        if (lcount >= EXTRACT_BUF) // block-uniform (read after the barrier)
+            extract_flush(lbuf, &lcount, counter, out, cap, &sh_base);
+    }
+    extract_flush(lbuf, &lcount, counter, out, cap, &sh_base);
+    if (blockIdx.x == 0 && threadIdx.x < (nw & 3)) {
+        const uint64_t i = nq * 4 + threadIdx.x;
+        uint32_t x = bits[w0 + i];
+        while (x) {
+            const int b = __ffs(x) - 1;
+            x &= x - 1u;
+            const unsigned long long pos = atomicAdd(counter, 1ull);
             if (pos < cap)
                 out[pos] = ((w0 + i) << 5) + (uint64_t)b;
-            pos++;
         }
     }
 }
@@ -756,8 +819,8 @@ int brx_set_extract_keys_device(const brx_set_t *set, uint64_t first_hash, uint6
         return BRX_ERR_ARG;
     }
     const uint64_t nbits = set->nwords * 32;
-    if ((first_hash & 31u) || (n_hashes & 31u) || first_hash + n_hashes > nbits) {
-        set_error("extract range must be 32-aligned and inside the set");
+    if ((first_hash & 127u) || (n_hashes & 31u) || first_hash + n_hashes > nbits) {
+        set_error("extract range must start on a multiple of 128 hashes, span a multiple of 32, and lie inside the set");
         return BRX_ERR_ARG;
     }
     BRX_TRY(use_device(set->device));
@@ -768,7 +831,7 @@ int brx_set_extract_keys_device(const brx_set_t *set, uint64_t first_hash, uint6
     const uint64_t nw = n_hashes / 32;
     if (e == hipSuccess && nw) {
         KernelTimer t("extract_keys", s);
-        extract_kernel<<<grid_for(nw, 256, 256 * 8), 256, 0, s>>>(set->d_bits, first_hash / 32, nw, d_cnt, d_out, cap);
+        extract_kernel<<<grid_for(nw / 4 + 1, 256, 256 * 8), 256, 0, s>>>(set->d_bits, first_hash / 32, nw, d_cnt, d_out, cap);
     }
     unsigned long long n = 0;
     if (e == hipSuccess)

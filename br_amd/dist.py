@@ -14,6 +14,7 @@ counts_tensor()), so the world_size-2 gloo tests drive exactly this code on CPU 
 """
 from __future__ import annotations
 
+import os
 from typing import Optional
 
 import torch
@@ -82,14 +83,13 @@ class SetExchange:
         """dense strategy: in-place all-reduce of the u8 table; the caller thresholds afterwards"""
         allreduce_counts(GpuCounterAdapter(counter), abundance, self.world, stream)
 
-    def build_partitioned(self, local, owned, solid, abundance: int, stream: Optional[int] = None) -> None:
-        """partitioned strategy: `local` has counted this rank's reads; on return `solid` holds the
-        set of ALL ranks' reads"""
-        owned.reset(stream)
-        eng = GpuPartitionedEngine(local, owned, solid, stream)
+    def build_partitioned(self, counter, solid, abundance: int, stream: Optional[int] = None) -> None:
+        """partitioned strategy: `counter` has counted this rank's reads (one add_batch); on return
+        `solid` holds the set of ALL ranks' reads and the counter is empty again"""
+        eng = GpuPartitionedEngine(counter, solid, stream)
         exchange_partitioned(eng, abundance, self.world, self.rank)
         torch.cuda.current_stream().synchronize()
-        owned.reset(stream)
+        counter.reset(stream)
         eng.release()
 
 
@@ -116,6 +116,45 @@ def owner_bounds(n_buckets: int, world: int):
     return [r * n_buckets // world for r in range(world + 1)]
 
 
+A2A_CHUNK_ELEMS = 1 << 27  # per peer and per call: 512 MiB of int32 keys
+
+
+def all_to_all_chunked(recv: torch.Tensor, send: torch.Tensor, recv_counts, send_counts, chunk: Optional[int] = None) -> None:
+    """all_to_all_single with per-peer messages capped at `chunk` elements.  One 4 GB message per peer
+    (1e9 int32 keys, the single-rank case of the k=19 / 1 Gbp job) was observed to arrive TRUNCATED at
+    2^31 bytes through torch.distributed + RCCL on this stack, silently; smaller pieces are exact."""
+    chunk = chunk or A2A_CHUNK_ELEMS
+    world = len(send_counts)
+    send_off = [0]
+    recv_off = [0]
+    for r in range(world):
+        send_off.append(send_off[-1] + send_counts[r])
+        recv_off.append(recv_off[-1] + recv_counts[r])
+    rounds = max([(c + chunk - 1) // chunk for c in list(send_counts) + list(recv_counts)] + [0])
+    # every rank must run the same number of rounds
+    t = torch.tensor([rounds], dtype=torch.int64, device=send.device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    rounds = int(t.item())
+    for c in range(rounds):
+        s_parts, r_sizes, s_sizes = [], [], []
+        for r in range(world):
+            lo = min(c * chunk, send_counts[r])
+            hi = min((c + 1) * chunk, send_counts[r])
+            s_parts.append(send[send_off[r] + lo:send_off[r] + hi])
+            s_sizes.append(hi - lo)
+            lo = min(c * chunk, recv_counts[r])
+            hi = min((c + 1) * chunk, recv_counts[r])
+            r_sizes.append(hi - lo)
+        sbuf = torch.cat(s_parts) if world > 1 else s_parts[0].contiguous()
+        rbuf = torch.empty(sum(r_sizes), dtype=recv.dtype, device=recv.device)
+        dist.all_to_all_single(rbuf, sbuf, output_split_sizes=r_sizes, input_split_sizes=s_sizes)
+        pos = 0
+        for r in range(world):
+            lo = min(c * chunk, recv_counts[r])
+            recv[recv_off[r] + lo:recv_off[r] + lo + r_sizes[r]] = rbuf[pos:pos + r_sizes[r]]
+            pos += r_sizes[r]
+
+
 def exchange_partitioned(engine, abundance: int, world: int, rank: int) -> None:
     """engine protocol (GPU: GpuPartitionedEngine below; tests drive it with CPU tensors over gloo):
        l1() -> (keys int32[n], l1off int64[B1+1]); add_segment(keys, l1off); finish(abundance);
@@ -131,8 +170,7 @@ def exchange_partitioned(engine, abundance: int, world: int, rank: int) -> None:
     lo, hi = bounds[rank], bounds[rank + 1]
     recv_counts = [int(t[hi] - t[lo]) for t in tab_h]
     recv = torch.empty(sum(recv_counts), dtype=keys.dtype, device=keys.device)
-    dist.all_to_all_single(recv, keys[:sum(send_counts)].contiguous(), output_split_sizes=recv_counts,
-                           input_split_sizes=send_counts)
+    all_to_all_chunked(recv, keys[:sum(send_counts)], recv_counts, send_counts)
     pos = 0
     for s in range(world):
         t = tables[s]
@@ -158,40 +196,43 @@ def exchange_partitioned(engine, abundance: int, world: int, rank: int) -> None:
 
 
 class GpuPartitionedEngine:
-    """exchange_partitioned's engine over two br_amd.Counter objects (partitioned strategy): `local`
-    has counted this rank's reads, `owned` receives the segments of the owned digit range."""
+    """exchange_partitioned's engine over ONE br_amd.Counter (partitioned strategy): it has counted this
+    rank's reads (level 1); after the keys have been exchanged it is reset and re-used to finish the
+    segments of the owned digit range, so the radix workspace is allocated once."""
 
-    def __init__(self, local, owned, solid, stream: Optional[int] = None):
-        self.local, self.owned, self.solid, self.stream = local, owned, solid, stream
+    def __init__(self, counter, solid, stream: Optional[int] = None):
+        self.counter, self.solid, self.stream = counter, solid, stream
         self.n_hashes = solid.n_hashes()
         self._keep = []
-        self._scratch = None
+        self._sent = False
 
     def l1(self):
-        pk, po, nb, nk = self.local.l1_view()
+        pk, po, nb, nk = self.counter.l1_view()
         keys = device_view(pk, max(nk, 1) * 4).view(torch.int32)[:nk]
         l1off = device_view(po, (nb + 1) * 8).view(torch.int64)
         return keys, l1off
 
     def add_segment(self, keys: torch.Tensor, l1off: torch.Tensor) -> None:
+        if not self._sent:
+            # the all_to_all that read the local level-1 buffer has been issued on this stream; make sure
+            # it is complete before the counter forgets (and later re-uses) that buffer
+            torch.cuda.current_stream().synchronize()
+            self.counter.reset(self.stream)
+            self._sent = True
         self._keep.append((keys, l1off))
         if keys.numel():
-            self.owned.add_partitioned_device(keys.data_ptr(), l1off.data_ptr(), keys.numel())
+            self.counter.add_partitioned_device(keys.data_ptr(), l1off.data_ptr(), keys.numel())
 
     def finish(self, abundance: int) -> None:
-        self.owned.finish_into(abundance, self.solid, self.stream)
+        self.counter.finish_into(abundance, self.solid, self.stream)
 
     def extract(self, first_hash: int, n_hashes: int) -> torch.Tensor:
-        cap = 1 << 20
-        while True:
-            buf = torch.empty(cap, dtype=torch.int64, device="cuda")
-            try:
-                n = self.solid.extract_keys_device(first_hash, n_hashes, buf.data_ptr(), cap, self.stream)
-                return buf[:n]
-            except Exception as e:  # BRX_ERR_OVERFLOW: retry with the size the kernel reported
-                if getattr(e, "status", 0) != -7:
-                    raise
-                cap *= 8
+        # everything outside the owned range is still zero, so the whole-set popcount sizes the list
+        torch.cuda.current_stream().synchronize()
+        cap = self.solid.popcount() + 64
+        buf = torch.empty(cap, dtype=torch.int64, device="cuda")
+        n = self.solid.extract_keys_device(first_hash, n_hashes, buf.data_ptr(), cap, self.stream)
+        return buf[:n]
 
     def or_keys(self, keys: torch.Tensor) -> None:
         keys = keys.contiguous()
@@ -199,6 +240,5 @@ class GpuPartitionedEngine:
         self.solid.or_keys_device(keys.data_ptr(), keys.numel(), self.stream)
 
     def release(self) -> None:
-        """drop the references that kept received segments alive (call after the set is final and the
-        owned counter has been reset)"""
+        """drop the references that kept received segments alive (after the set is final)"""
         self._keep.clear()

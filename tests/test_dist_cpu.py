@@ -124,6 +124,7 @@ def _part_worker(rank, world, port, k, abundance, q):
     reads = read_fasta(os.path.join(ROOT, "tests", "golden", "raw.fasta"))[1][:50] + [b"", b"ACGT"]
     lo, hi = bd.shard_range(len(reads), world, rank)
     eng = NumpyPartEngine(k, reads[lo:hi], l1_bits=3)
+    bd.A2A_CHUNK_ELEMS = 4099   # force many all_to_all rounds (the cap is a constant shared by all ranks)
     bd.exchange_partitioned(eng, abundance, world, rank)
     ref = O.Solid.from_count(k, O.count_reads(k, reads), abundance)
     mine = np.packbits(eng.bits, bitorder="little").tobytes()

@@ -470,7 +470,6 @@ def test_build_partitioned_over_rccl_single_rank(raw_reads):
     try:
         stream = torch.cuda.current_stream().cuda_stream
         local = br_amd.Counter(k, 0, _lib.COUNT_SORTED)
-        owned = br_amd.Counter(k, 0, _lib.COUNT_SORTED)
         solid = br_amd.Pcon.new(k)
         bases, offs = br_amd.pack_reads(reads)
         db = torch.from_numpy(bases.copy()).cuda()
@@ -478,7 +477,7 @@ def test_build_partitioned_over_rccl_single_rank(raw_reads):
         for _ in range(2):  # twice: the bench resets and reuses the same objects every step
             local.reset(stream)
             local.add_batch_device(db.data_ptr(), do.data_ptr(), len(reads), int(offs[-1]), stream)
-            bd.SetExchange(1, 0).build_partitioned(local, owned, solid, a, stream)
+            bd.SetExchange(1, 0).build_partitioned(local, solid, a, stream)
             torch.cuda.synchronize()
             ref = O.Solid.from_count(k, O.count_reads(k, reads), a)
             assert solid.to_solid_bytes() == ref.to_bytes()
