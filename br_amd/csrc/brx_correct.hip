@@ -23,6 +23,7 @@
 // (capacity = input length * (1 + slack/4) + 64); the reverse pass reads its input back to
 // front instead of materialising a reversed copy (src/lib.rs:111 reverses, does not complement).
 #include "brx_internal.hpp"
+#include "brx_index.hpp"
 
 #include <stdlib.h>
 #include <string.h>
@@ -44,6 +45,7 @@ enum { CTL_WORK = 0, CTL_OVERFLOW = 1, CTL_ROUNDS = 2, CTL_PROBES = 3, CTL_TRIGG
 
 struct PassParams {
     const uint32_t *bits;
+    IdxView idx;      // lines == nullptr: every probe goes to the bitset
     int k;
     int c;            // confirm
     uint32_t n_reads;
@@ -62,7 +64,8 @@ struct PassParams {
     uint64_t *path_k;
     uint32_t maxpath;
     // greedy (greedy.rs): max_search and the per-group LDS carve-up for the alignment
-    uint32_t flags;       // tuning switches for A/B runs (BRX_TUNE): 1 no look-ahead reuse, 2 four ALTS probes, 4 unstaged SCEN
+    uint32_t flags;       // tuning switches for A/B runs (BRX_TUNE): 1 no look-ahead reuse, 2 four ALTS probes, 4 unstaged SCEN,
+                          // 16 state scheduler (one state per round; measured slower, kept for experiments)
     int max_search;
     uint32_t g_dim;       // max (m+1), (n+1) of the DP = k + max_search + 2
     uint32_t g_lds_bytes; // bytes of dynamic LDS per group
@@ -79,7 +82,18 @@ __device__ __forceinline__ bool probe(const uint32_t *__restrict__ bits, uint64_
     return (bits[h >> 5] >> (h & 31u)) & 1u;
 }
 
-enum { ST_INIT = 0, ST_SCAN, ST_ERRLEN, ST_ALTS, ST_SCEN, ST_MORE, ST_WALK, ST_T1, ST_TSCORE, ST_TMORE, ST_GFOLLOW, ST_GVALID };
+enum { ST_INIT = 0, ST_SCAN, ST_ERRLEN, ST_ALTS, ST_SCEN, ST_MORE, ST_WALK, ST_T1, ST_TSCORE, ST_TMORE, ST_GFOLLOW, ST_GVALID, ST_COUNT };
+constexpr uint32_t AGE_LIMIT = 6;
+
+// states a kernel instance of method M can be in (prunes the scheduler's per-state ballots)
+template <int M>
+__device__ constexpr bool state_reachable(int x)
+{
+    const bool errlen = (M == BRX_GRAPH || M == BRX_GAP_SIZE), one = (M == BRX_ONE || M == BRX_GAP_SIZE);
+    return x == ST_INIT || x == ST_SCAN || x == ST_ALTS || (x == ST_ERRLEN && errlen) || ((x == ST_SCEN || x == ST_MORE) && one) ||
+           (x == ST_WALK && errlen) || ((x == ST_T1 || x == ST_TSCORE || x == ST_TMORE) && M == BRX_TWO) ||
+           ((x == ST_GFOLLOW || x == ST_GVALID) && M == BRX_GREEDY);
+}
 enum { MODE_ONE = 0, MODE_GRAPH = 1, MODE_INSSUB = 2, MODE_TWO = 3 };
 
 // ---- ScenarioTwo (src/correct/exist/two.rs:34-328), ids in declaration order ---------------------
@@ -321,7 +335,9 @@ __device__ __forceinline__ uint32_t scen_width(uint32_t sub, uint32_t c, int G, 
 }
 
 template <int G, int M>
-__global__ __launch_bounds__(256) void correct_kernel(PassParams p)
+// One fits 80 VGPRs without spilling: 6 waves per SIMD instead of 5 (the kernel waits on memory 60 % of the
+// time, measured 8 % faster); the other methods keep the compiler's own choice
+__global__ __launch_bounds__(256, (M == BRX_ONE ? 6 : 1)) void correct_kernel(PassParams p)
 {
     constexpr bool HAS_ERRLEN = (M == BRX_GRAPH || M == BRX_GAP_SIZE);
     constexpr bool HAS_ONE = (M == BRX_ONE || M == BRX_GAP_SIZE);
@@ -353,6 +369,8 @@ __global__ __launch_bounds__(256) void correct_kernel(PassParams p)
     int st = ST_INIT, mode = HAS_TWO ? MODE_TWO : (M == BRX_GRAPH ? MODE_GRAPH : MODE_ONE);
     uint32_t sub = 0, failmask = 0, passmask = 0;
     uint8_t ch_t = 0;
+    bool slow = false; // this round is the bitset re-run of a round the probe index could not answer
+    bool was_unres = false, kept_sol = false; // per lane: its probe of that round was unanswered / its answer
     // error_len / walk state
     uint32_t elen = 0, ej = 0, npath = 0, gap = 0;
     uint64_t fc = 0, ek = 0, wk = 0;
@@ -469,7 +487,39 @@ __global__ __launch_bounds__(256) void correct_kernel(PassParams p)
 
     fetch();
 
-    while (__any(have)) {
+    uint32_t wait = 0; // rounds this group has been passed over by the state scheduler
+    for (;;) {
+        // ---------------- phase 0: which state runs this round -------------------------------
+        // The groups of a wave sit in different states, and code of a state costs the wave the same
+        // whether one group or all of them execute it.  So a round serves ONE state: the one most
+        // groups are in (a group passed over AGE_LIMIT times in a row goes first).  Groups in other
+        // states idle for the round; they pile up in their state and are served together later.
+        const bool leader = have && gl == 0;
+        const uint64_t lead = __ballot(leader);
+        if (!lead)
+            break;
+        int run_st = -1;
+        if (p.flags & 16u) {
+            const uint64_t starving = __ballot(leader && wait >= AGE_LIMIT);
+            if (starving) {
+                run_st = __shfl(st, __builtin_ctzll(starving));
+            } else {
+                int best = 0;
+#pragma unroll
+                for (int x = 0; x < ST_COUNT; x++) {
+                    if (!state_reachable<M>(x))
+                        continue;
+                    const int cnt = __builtin_popcountll(__ballot(leader && st == x));
+                    if (cnt > best) {
+                        best = cnt;
+                        run_st = x;
+                    }
+                }
+            }
+        }
+        const bool act = have && (run_st < 0 || st == run_st);
+        wait = (have && !act) ? wait + 1u : 0u;
+
         bool do_probe = false;
         uint64_t pk = 0;
         uint8_t ch = 0;
@@ -477,7 +527,7 @@ __global__ __launch_bounds__(256) void correct_kernel(PassParams p)
         bool sc_active = false;
 
         // ---------------- phase 1: choose this round's probe --------------------------------
-        if (have) {
+        if (act) {
             n_rounds += (gl == 0);
             if (st == ST_INIT) {
                 if (n < (uint32_t)k) {
@@ -614,13 +664,41 @@ __global__ __launch_bounds__(256) void correct_kernel(PassParams p)
                     do_probe = true;
                 }
             }
-            if (HAS_GREEDY && ++steps > (1u << 24))
+            // runaway guard: no read needs anywhere near this many rounds (greedy can move the read cursor
+            // backwards for ever on some inputs -- the reference spins; a logic error must not hang the GPU)
+            if (++steps > (1u << 24) + 64u * n)
                 do_probe = false;
         }
 
         // ---------------- phase 2: one probe per lane, whole wave at once ---------------------
         bool sol = false;
-        if (do_probe) {
+        bool retry = false;
+        if (p.idx.lines) {
+            // probe index (brx_index.hpp): the line of the k-mer's minimizer, shared by the neighbouring
+            // lanes.  A line that overflowed at build time cannot say "absent": the GROUP then repeats
+            // this round against the bitset (phase 1 is a pure function of the group state, so the next
+            // iteration recomputes the same probes); the other groups of the wave carry on.
+            bool unres = false;
+            if (do_probe) {
+                if (!slow) {
+                    const int pr = index_probe(p.idx, pk, k);
+                    sol = pr == 1;
+                    unres = pr == 2;
+                    n_probes++;
+                } else if (was_unres) {
+                    sol = probe(p.bits, pk, k);
+                    n_probes++;
+                } else {
+                    sol = kept_sol; // answered by the index in the round being repeated
+                }
+            }
+            retry = ((__ballot(unres) >> gshift) & GM) != 0ull;
+            if (act) { // a group the scheduler passed over keeps its pending re-run
+                slow = retry;
+                was_unres = unres;
+                kept_sol = sol;
+            }
+        } else if (do_probe) {
             sol = probe(p.bits, pk, k);
             n_probes++;
         }
@@ -628,7 +706,7 @@ __global__ __launch_bounds__(256) void correct_kernel(PassParams p)
         const uint64_t gmask = (ball >> gshift) & GM;
 
         // ---------------- phase 3: group-uniform transitions ----------------------------------
-        if (have) {
+        if (act && !retry) {
             bool fail = false;   // correct_error returned None
             int apply_s = -1;    // One scenario to apply
             int apply_t = -1;    // Two scenario to apply
@@ -989,7 +1067,7 @@ __global__ __launch_bounds__(256) void correct_kernel(PassParams p)
                     }
                 }
             }
-            if (HAS_GREEDY && have && steps > (1u << 24)) {
+            if (have && steps > (1u << 24) + 64u * n) {
                 fail = false;
                 apply_s = apply_t = -1;
                 apply_path = false;
@@ -1146,7 +1224,7 @@ int ensure(void **p, uint64_t *cap, uint64_t need)
     return BRX_OK;
 }
 
-int group_width(bool reverse_pass = false)
+int group_width(bool reverse_pass = false, bool indexed = false)
 {
     // lanes per read; BRX_GROUP / BRX_GROUP_REV override (read on every launch so tests can sweep them).
     // The reverse pass of run_correction (src/lib.rs:48-55) sees almost only non-solid k-mers and hardly
@@ -1154,7 +1232,9 @@ int group_width(bool reverse_pass = false)
     const char *e = getenv(reverse_pass ? "BRX_GROUP_REV" : "BRX_GROUP");
     if (!e && reverse_pass)
         e = getenv("BRX_GROUP");
-    const int dflt = reverse_pass ? 64 : 16; // measured: profiles (ab_correct), +3 % over 16/16
+    // measured (tools/ab_correct.py): bitset probes 16/64 (+3 % over 16/16); with the probe index the shared
+    // probe code is the larger part of a round and 8 groups per wave amortise it better: 8/64 (+5 % over 16/64)
+    const int dflt = reverse_pass ? 64 : (indexed ? 8 : 16);
     const int g = e ? atoi(e) : dflt;
     return (g == 8 || g == 16 || g == 32 || g == 64) ? g : dflt;
 }
@@ -1338,10 +1418,16 @@ int brx_chain_correct_batch_device(brx_chain_t *ch, const uint8_t *d_bases, cons
         ch->scan_tmp_cap = tmp_bytes;
     }
 
+    // probe index of the set (built here when the set has none yet, e.g. after a finish_into)
+    BRX_TRY(index_ensure(ch->set, s));
+    IdxView idx{nullptr, 0, 0, 0};
+    if (ch->set->idx_valid && index_wanted(k))
+        idx = IdxView{ch->set->d_lines, 32u - ch->set->idx_log_lines, ch->set->idx_m, (uint32_t)k - ch->set->idx_m + 1u};
+
     const int n_dirs = ch->two_side ? 1 : 2;
     const int n_methods = (int)ch->methods.size();
     uint64_t stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    const int G = group_width();
+    const int G = group_width(false, idx.lines != nullptr);
     bool needs_path = false;
     for (int m = 0; m < n_methods; m++)
         needs_path |= (ch->methods[m].method == BRX_GRAPH || ch->methods[m].method == BRX_GAP_SIZE ||
@@ -1380,6 +1466,7 @@ int brx_chain_correct_batch_device(brx_chain_t *ch, const uint8_t *d_bases, cons
             for (int m = 0; m < n_methods; m++) {
                 PassParams p;
                 p.bits = ch->set->d_bits;
+                p.idx = idx;
                 p.k = k;
                 p.c = ch->methods[m].confirm;
                 p.n_reads = n_reads;
@@ -1412,7 +1499,7 @@ int brx_chain_correct_batch_device(brx_chain_t *ch, const uint8_t *d_bases, cons
         BRX_HIP(hipStreamSynchronize(s));
         stats[4] = attempt;
         if (ch->h_ctrl[CTL_NONTERM] != 0) {
-            set_error("%llu read(s): the scan does not terminate (greedy moved the read cursor backwards for ever; "
+            set_error("%llu read(s): the scan does not terminate (e.g. greedy moving the read cursor backwards for ever; "
                       "the reference spins on such input)", (unsigned long long)ch->h_ctrl[CTL_NONTERM]);
             return BRX_ERR_UNSUPPORTED;
         }

@@ -1,0 +1,310 @@
+// Probe index of a solid set: build + test entry points (layout and probe in brx_index.hpp).
+#include "brx_internal.hpp"
+#include "brx_index.hpp"
+
+#include <stdlib.h>
+
+using namespace brx;
+
+namespace {
+
+// one key per thread: claim a slot of the key's line, or flag the line as overflowed
+__global__ __launch_bounds__(256) void index_insert_kernel(const uint64_t *__restrict__ keys, uint64_t n, uint64_t *__restrict__ lines,
+                                                           uint32_t line_shift, uint32_t m, uint32_t w, int k,
+                                                           unsigned long long *__restrict__ n_overflow)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    uint32_t lost = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint64_t h = keys[i];
+        const uint64_t canon = (h << 1) | (uint64_t)(popc64(h) & 1); // even popcount (brx_kmer.hpp)
+        const uint64_t rc = revcomp(canon, k);
+        const uint32_t line = index_line_of(minimizer_of(canon, rc, m, w), line_shift);
+        unsigned long long *L = reinterpret_cast<unsigned long long *>(lines) + (uint64_t)line * 8ull;
+        const unsigned long long seen = __hip_atomic_load(L + 7, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint32_t slot = IDX_SLOTS;
+        if ((uint32_t)seen < (uint32_t)IDX_SLOTS) // full lines are not counted further: the counter stays small
+            slot = (uint32_t)atomicAdd(L + 7, 1ull);
+        if (slot < (uint32_t)IDX_SLOTS) {
+            L[slot] = h + 1ull;
+        } else {
+            if (!(seen & IDX_OVERFLOW))
+                atomicOr(L + 7, (unsigned long long)IDX_OVERFLOW);
+            lost++;
+        }
+    }
+    for (int d = 32; d > 0; d >>= 1)
+        lost += __shfl_down(lost, d);
+    if ((threadIdx.x & 63) == 0 && lost)
+        atomicAdd(n_overflow, (unsigned long long)lost);
+}
+
+__global__ void index_get_kernel(IdxView v, const uint32_t *__restrict__ bits, const uint64_t *__restrict__ kmers, uint32_t n, int k,
+                                 uint8_t *__restrict__ out, unsigned long long *__restrict__ n_fallback)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    const uint64_t fwd = kmers[i] & kmask(k);
+    int r = index_probe(v, fwd, k);
+    if (r == 2) {
+        const uint64_t h = khash(fwd, k);
+        r = (bits[h >> 5] >> (h & 31u)) & 1u;
+        atomicAdd(n_fallback, 1ull);
+    }
+    out[i] = (uint8_t)r;
+}
+
+int env_int(const char *name, int dflt)
+{
+    const char *e = getenv(name);
+    return (e && *e) ? atoi(e) : dflt;
+}
+
+} // namespace
+
+namespace brx {
+
+bool index_wanted(int k)
+{
+    // below k = 15 the whole bitset (<= 4 MiB at k = 13) lives in every XCD's L2 and a plain probe is cheaper
+    // (BRX_INDEX_MIN_K lowers the threshold: the parity tests run every corrector through the index at small k)
+    return (k & 1) && k >= env_int("BRX_INDEX_MIN_K", 15) && k >= 5 && env_int("BRX_INDEX", 1) != 0;
+}
+
+// smallest odd m whose 4^m / 2 canonical m-mers outnumber the keys 16 to 1 (a minimizer shared by many
+// genome positions piles all their k-mers into one line), at least 2 windows
+int index_auto_m(int k, uint64_t n_keys)
+{
+    int m = 3;
+    while (m < IDX_MAX_M && (1ull << (2 * m - 1)) < 16ull * n_keys)
+        m += 2;
+    if (m > k - 2)
+        m = k - 2;
+    if (k - m + 1 > 16)
+        m = k - 15;
+    if (!(m & 1))
+        m++;
+    return m < 3 ? 3 : m;
+}
+
+int index_build_from_keys(brx_set *set, const uint64_t *d_keys, uint64_t n, int m, int log_lines, hipStream_t s)
+{
+    const int k = set->k;
+    if (!(k & 1) || k < 5 || k > 31) {
+        set_error("probe index needs odd 5 <= k <= 31 (k=%d)", k);
+        return BRX_ERR_UNSUPPORTED;
+    }
+    BRX_TRY(use_device(set->device));
+    if (m <= 0)
+        m = env_int("BRX_INDEX_M", 0);
+    if (m <= 0)
+        m = index_auto_m(k, n);
+    if (!(m & 1) || m < 3 || m > IDX_MAX_M || k - m + 1 < 2 || k - m + 1 > 16) {
+        set_error("probe index: minimizer length %d must be odd, 3..%d, with 2..16 windows in a %d-mer", m, IDX_MAX_M, k);
+        return BRX_ERR_ARG;
+    }
+    if (log_lines <= 0)
+        log_lines = env_int("BRX_INDEX_LOG_LINES", 0);
+    if (log_lines <= 0) {
+        // about one key per 7-slot line: a minimizer brings up to k-m+1 keys at once, and a line that
+        // overflows costs its probes a second round
+        log_lines = 10;
+        while (log_lines < 28 && (1ull << log_lines) < n + n / 2)
+            log_lines++;
+    }
+    if (log_lines < 4 || log_lines > 30) {
+        set_error("probe index: log2(lines)=%d out of range 4..30", log_lines);
+        return BRX_ERR_ARG;
+    }
+    std::lock_guard<std::mutex> g(set->idx_mu);
+    set->idx_valid = false;
+    const uint64_t n_lines = 1ull << log_lines;
+    if (set->lines_alloc < n_lines) {
+        if (set->d_lines)
+            (void)hipFree(set->d_lines);
+        set->d_lines = nullptr;
+        set->lines_alloc = 0;
+        hipError_t e = hipMalloc((void **)&set->d_lines, n_lines * 64ull);
+        if (e != hipSuccess) {
+            set_error("hipMalloc(%llu B probe index): %s", (unsigned long long)(n_lines * 64ull), hipGetErrorString(e));
+            return BRX_ERR_NOMEM;
+        }
+        set->lines_alloc = n_lines;
+    }
+    unsigned long long *d_ovf = nullptr;
+    BRX_HIP(hipMalloc((void **)&d_ovf, 8));
+    hipError_t e = hipMemsetAsync(d_ovf, 0, 8, s);
+    if (e == hipSuccess) {
+        KernelTimer t("index_zero", s);
+        e = hipMemsetAsync(set->d_lines, 0, n_lines * 64ull, s);
+    }
+    if (e == hipSuccess && n) {
+        KernelTimer t("index_insert", s);
+        uint64_t blocks = (n + 255) / 256;
+        if (blocks > 256 * 16)
+            blocks = 256 * 16;
+        index_insert_kernel<<<(int)blocks, 256, 0, s>>>(d_keys, n, set->d_lines, 32u - (uint32_t)log_lines, (uint32_t)m,
+                                                        (uint32_t)(k - m + 1), k, d_ovf);
+        e = hipGetLastError();
+    }
+    unsigned long long ovf = 0;
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(&ovf, d_ovf, 8, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess)
+        e = hipStreamSynchronize(s);
+    (void)hipFree(d_ovf);
+    if (e != hipSuccess) {
+        set_error("probe index build: %s", hipGetErrorString(e));
+        return BRX_ERR_HIP;
+    }
+    set->idx_log_lines = (uint32_t)log_lines;
+    set->idx_m = (uint32_t)m;
+    set->idx_keys = n;
+    set->idx_overflow_keys = ovf;
+    set->idx_valid = true;
+    return BRX_OK;
+}
+
+int index_ensure(const brx_set *cset, hipStream_t s)
+{
+    brx_set *set = const_cast<brx_set *>(cset);
+    if (set->idx_valid || set->idx_declined || !index_wanted(set->k))
+        return BRX_OK;
+    BRX_TRY(use_device(set->device));
+    uint64_t n = 0;
+    bool listed = false;
+    if (set->keylist_valid) {
+        unsigned long long nl = 0;
+        BRX_HIP(hipMemcpyAsync(&nl, set->d_keylist_n, 8, hipMemcpyDeviceToHost, s));
+        BRX_HIP(hipStreamSynchronize(s));
+        listed = nl <= set->keylist_cap; // a truncated list is useless
+        n = nl;
+    }
+    if (!listed) {
+        BRX_HIP(hipStreamSynchronize(s)); // the bits may still be in flight on `s`; popcount runs on the null stream
+        BRX_TRY(brx_set_popcount(set, &n));
+    }
+    if (set->k - index_auto_m(set->k, n) + 1 < 3 && env_int("BRX_INDEX_M", 0) <= 0) {
+        // so many keys that a safe minimizer is (nearly) the k-mer itself: neighbours would not share lines
+        set->idx_declined = true;
+        return BRX_OK;
+    }
+    if (listed)
+        return index_build_from_keys(set, set->d_keylist, n, 0, 0, s);
+    uint64_t *d_keys = nullptr;
+    BRX_HIP(hipMalloc((void **)&d_keys, (n ? n : 1) * 8));
+    uint64_t got = 0;
+    int st = brx_set_extract_keys_device(set, 0, set->nwords * 32, d_keys, n, &got, s);
+    if (st == BRX_OK)
+        st = index_build_from_keys(set, d_keys, got, 0, 0, s);
+    (void)hipFree(d_keys);
+    return st;
+}
+
+} // namespace brx
+
+extern "C" {
+
+int brx_set_index_build(brx_set_t *set, int m, int log2_lines, void *stream)
+{
+    if (!set)
+        return BRX_ERR_ARG;
+    BRX_TRY(use_device(set->device));
+    BRX_HIP(hipStreamSynchronize((hipStream_t)stream));
+    uint64_t n = 0;
+    BRX_TRY(brx_set_popcount(set, &n));
+    uint64_t *d_keys = nullptr;
+    BRX_HIP(hipMalloc((void **)&d_keys, (n ? n : 1) * 8));
+    uint64_t got = 0;
+    int st = brx_set_extract_keys_device(set, 0, set->nwords * 32, d_keys, n, &got, stream);
+    if (st == BRX_OK)
+        st = index_build_from_keys(set, d_keys, got, m, log2_lines, (hipStream_t)stream);
+    (void)hipFree(d_keys);
+    return st;
+}
+
+int brx_set_index_build_from_keys_device(brx_set_t *set, const uint64_t *d_keys, uint64_t n, int m, int log2_lines, void *stream)
+{
+    if (!set || (!d_keys && n))
+        return BRX_ERR_ARG;
+    return index_build_from_keys(set, d_keys, n, m, log2_lines, (hipStream_t)stream);
+}
+
+int brx_set_index_drop(brx_set_t *set)
+{
+    if (!set)
+        return BRX_ERR_ARG;
+    std::lock_guard<std::mutex> g(set->idx_mu);
+    set->idx_valid = false;
+    if (set->d_lines && use_device(set->device) == BRX_OK)
+        (void)hipFree(set->d_lines);
+    set->d_lines = nullptr;
+    set->lines_alloc = 0;
+    return BRX_OK;
+}
+
+int brx_set_index_info(const brx_set_t *set, uint64_t *info8)
+{
+    if (!set || !info8)
+        return BRX_ERR_ARG;
+    for (int i = 0; i < 8; i++)
+        info8[i] = 0;
+    info8[0] = set->idx_valid ? 1 : 0;
+    if (set->idx_valid) {
+        info8[1] = set->idx_m;
+        info8[2] = set->idx_log_lines;
+        info8[3] = set->idx_keys;
+        info8[4] = set->idx_overflow_keys;
+        info8[5] = (1ull << set->idx_log_lines) * 64ull;
+    }
+    return BRX_OK;
+}
+
+int brx_set_get_batch_indexed(const brx_set_t *set, const uint64_t *forward_kmers, uint32_t n, uint8_t *out, uint64_t *n_fallback)
+{
+    if (!set || (!forward_kmers && n) || (!out && n))
+        return BRX_ERR_ARG;
+    if (!set->idx_valid) {
+        set_error("get_batch_indexed: the set has no probe index (brx_set_index_build)");
+        return BRX_ERR_ARG;
+    }
+    BRX_TRY(use_device(set->device));
+    if (n_fallback)
+        *n_fallback = 0;
+    if (!n)
+        return BRX_OK;
+    uint64_t *d_k = nullptr;
+    uint8_t *d_o = nullptr;
+    unsigned long long *d_f = nullptr;
+    BRX_HIP(hipMalloc((void **)&d_k, (uint64_t)n * 8));
+    hipError_t e = hipMalloc((void **)&d_o, n);
+    if (e == hipSuccess)
+        e = hipMalloc((void **)&d_f, 8);
+    if (e == hipSuccess)
+        e = hipMemset(d_f, 0, 8);
+    if (e == hipSuccess)
+        e = hipMemcpy(d_k, forward_kmers, (uint64_t)n * 8, hipMemcpyHostToDevice);
+    unsigned long long fb = 0;
+    if (e == hipSuccess) {
+        IdxView v{set->d_lines, 32u - set->idx_log_lines, set->idx_m, (uint32_t)set->k - set->idx_m + 1u};
+        index_get_kernel<<<(n + 255) / 256, 256>>>(v, set->d_bits, d_k, n, set->k, d_o, d_f);
+        e = hipMemcpy(out, d_o, n, hipMemcpyDeviceToHost);
+        if (e == hipSuccess)
+            e = hipMemcpy(&fb, d_f, 8, hipMemcpyDeviceToHost);
+    }
+    (void)hipFree(d_k);
+    if (d_o)
+        (void)hipFree(d_o);
+    if (d_f)
+        (void)hipFree(d_f);
+    if (e != hipSuccess) {
+        set_error("get_batch_indexed: %s", hipGetErrorString(e));
+        return BRX_ERR_HIP;
+    }
+    if (n_fallback)
+        *n_fallback = fb;
+    return BRX_OK;
+}
+
+} // extern "C"

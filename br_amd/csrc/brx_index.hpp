@@ -1,0 +1,96 @@
+// Probe index: an HBM-locality layout of the solid set, used by the correction kernels.
+//
+// The reference's KmerSet::get (src/set/pcon.rs:189-191) is one bit of a 2^(2k-1)-bit vector, and the
+// canonical hashes of the k-mers a read walks through are unrelated: every get is its own 64-byte
+// memory transaction, and MI355X sustains ~55 G such transactions per second whatever the kernel does
+// (tools/line_probe_bench.hip).  The same tool shows that lanes of a wave reading the SAME line cost one
+// transaction.  So the solid k-mers are also stored in 64-byte lines addressed by the k-mer's
+// strand-symmetric MINIMIZER (smallest hashed canonical m-mer inside the k-mer): consecutive k-mers of a
+// read share their minimizer for (k-m+2)/2 positions on average and the lanes that probe them share the
+// line.  The index is exact: a line lists full keys; a line that could not take all its keys is flagged
+// and a probe it cannot answer is re-issued against the bitset, which stays the source of truth.
+//
+// Line layout (8 x u64): [0..6] key+1 of up to 7 k-mers (0 = empty; key = canonical >> 1),
+// [7] header: low 32 bits = number of insert attempts, bit 63 = overflowed.
+#pragma once
+#include "brx_kmer.hpp"
+
+namespace brx {
+
+constexpr int IDX_SLOTS = 7;
+constexpr uint64_t IDX_OVERFLOW = 1ull << 63;
+constexpr int IDX_MAX_M = 15; // a canonical m-mer must fit 30 bits (32-bit window arithmetic)
+
+struct IdxView {
+    const uint64_t *lines; // nullptr: no index, probe the bitset
+    uint32_t line_shift;   // 32 - log2(number of lines)
+    uint32_t m;            // minimizer length (odd, <= 15)
+    uint32_t w;            // k - m + 1 windows (2..16)
+};
+
+#if defined(__HIPCC__)
+
+// hash of the minimizer of a k-mer: min over its W m-mers of (min(m-mer, revcomp(m-mer)) * odd) mod 2^32,
+// an injective order of the canonical m-mers, so equal hashes mean equal minimizers.
+// The m-mer at bit offset 2j of fwd is the revcomp of the m-mer at bit offset 2(W-1-j) of rc, so the
+// value is the same for a k-mer and its reverse complement.
+template <int W>
+__device__ __forceinline__ uint32_t minimizer_hash_w(uint64_t fwd, uint64_t rc, uint32_t mm)
+{
+    const uint32_t flo = (uint32_t)fwd, fhi = (uint32_t)(fwd >> 32), rlo = (uint32_t)rc, rhi = (uint32_t)(rc >> 32);
+    uint32_t best = 0xffffffffu;
+#pragma unroll
+    for (int j = 0; j < W; j++) {
+        const uint32_t f = __builtin_amdgcn_alignbit(fhi, flo, 2 * j) & mm;
+        const uint32_t r = __builtin_amdgcn_alignbit(rhi, rlo, 2 * (W - 1 - j)) & mm;
+        const uint32_t c = f < r ? f : r;
+        const uint32_t h = c * 0x9E3779B1u;
+        best = h < best ? h : best;
+    }
+    return best;
+}
+
+__device__ __forceinline__ uint32_t minimizer_of(uint64_t fwd, uint64_t rc, uint32_t m, uint32_t w)
+{
+    const uint32_t mm = (1u << (2u * m)) - 1u;
+    switch (w) { // wave-uniform
+    case 2: return minimizer_hash_w<2>(fwd, rc, mm);
+    case 3: return minimizer_hash_w<3>(fwd, rc, mm);
+    case 4: return minimizer_hash_w<4>(fwd, rc, mm);
+    case 5: return minimizer_hash_w<5>(fwd, rc, mm);
+    case 6: return minimizer_hash_w<6>(fwd, rc, mm);
+    case 7: return minimizer_hash_w<7>(fwd, rc, mm);
+    case 8: return minimizer_hash_w<8>(fwd, rc, mm);
+    case 9: return minimizer_hash_w<9>(fwd, rc, mm);
+    case 10: return minimizer_hash_w<10>(fwd, rc, mm);
+    case 11: return minimizer_hash_w<11>(fwd, rc, mm);
+    case 12: return minimizer_hash_w<12>(fwd, rc, mm);
+    case 13: return minimizer_hash_w<13>(fwd, rc, mm);
+    case 14: return minimizer_hash_w<14>(fwd, rc, mm);
+    case 15: return minimizer_hash_w<15>(fwd, rc, mm);
+    default: return minimizer_hash_w<16>(fwd, rc, mm);
+    }
+}
+
+// the minimum of W hashes crowds the low end of the range: multiply once more before taking the top bits
+__device__ __forceinline__ uint32_t index_line_of(uint32_t mh, uint32_t line_shift)
+{
+    return (mh * 0x85EBCA6Bu) >> line_shift;
+}
+
+// 1 = present, 0 = absent, 2 = the line overflowed and does not hold the key: ask the bitset
+__device__ __forceinline__ int index_probe(const IdxView &v, uint64_t fwd, int k)
+{
+    const uint64_t rc = revcomp(fwd, k);
+    const uint64_t key = (((popc64(fwd) & 1) ? rc : fwd) >> 1) + 1ull;
+    const uint32_t line = index_line_of(minimizer_of(fwd, rc, v.m, v.w), v.line_shift);
+    const ulonglong2 *L = reinterpret_cast<const ulonglong2 *>(v.lines + (uint64_t)line * 8ull);
+    const ulonglong2 q0 = L[0], q1 = L[1], q2 = L[2], q3 = L[3];
+    // `|`, not `||`: with short-circuit evaluation the compiler loads slot 0 first and fetches the rest of
+    // the line only for the lanes that did not match it -- a second, dependent memory round trip
+    const bool found = (q0.x == key) | (q0.y == key) | (q1.x == key) | (q1.y == key) | (q2.x == key) | (q2.y == key) | (q3.x == key);
+    return found ? 1 : ((q3.y & IDX_OVERFLOW) ? 2 : 0);
+}
+#endif
+
+} // namespace brx

@@ -60,7 +60,33 @@ struct brx_set {
     int device;
     uint64_t nwords;   // u32 words
     uint32_t *d_bits;  // nwords, zero padded
+    // probe index over the same set (brx_index.hpp): built on demand, invalidated by every mutation
+    // of the bits that goes through the ABI
+    uint64_t *d_lines;       // 8 u64 per line
+    uint64_t lines_alloc;    // lines allocated
+    uint32_t idx_log_lines;
+    uint32_t idx_m;
+    bool idx_valid;
+    bool idx_declined;       // index_ensure looked at the set and found an index would not help
+    uint64_t idx_keys, idx_overflow_keys;
+    // solid hashes of the current bits, when the builder produced them on the side (partitioned finish)
+    uint64_t *d_keylist;
+    uint64_t keylist_cap;                 // entries
+    unsigned long long *d_keylist_n;      // device counter (may exceed keylist_cap: list truncated)
+    bool keylist_valid;
+    std::mutex idx_mu;
 };
+
+namespace brx {
+struct IdxView;
+// (re)builds the index from a device list of keys (bit indices = canonical >> 1); m / log_lines 0 = auto
+int index_build_from_keys(brx_set *set, const uint64_t *d_keys, uint64_t n, int m, int log_lines, hipStream_t s);
+// builds the index from the bitset when the set has none (no-op for k outside the indexed range)
+int index_ensure(const brx_set *set, hipStream_t s);
+inline void index_invalidate(brx_set *set) { set->idx_valid = false; set->idx_declined = false; set->keylist_valid = false; }
+int index_auto_m(int k, uint64_t n_keys);
+bool index_wanted(int k);
+}
 
 namespace brx { struct PartState; }
 

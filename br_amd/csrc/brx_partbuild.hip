@@ -446,17 +446,42 @@ constexpr uint32_t CHUNK_MAX = 65000;       // keys counted between two clamps (
 
 constexpr uint32_t STAGE_KEYS = 704;        // keys of a group of buckets staged in LDS per wave (4 blocks per CU)
 
+constexpr uint32_t EMIT_CAP = 256;          // solid hashes collected per wave between two appends to the key list
+
+// EMIT: also append every solid hash to a list (emit_keys, capacity emit_cap, counter emit_n keeps counting
+// past the capacity so the host can tell a truncated list).  The list feeds the probe index
+// (brx_index.hpp) without a second pass over the 2^(2k-1)-bit vector.
+template <bool EMIT>
 __global__ __launch_bounds__(64 * P3_WAVES) void final_count_kernel(const uint16_t *__restrict__ keys,
                                                                      const uint64_t *__restrict__ off, uint64_t n_buckets,
-                                                                     uint32_t abundance, uint32_t *__restrict__ bits)
+                                                                     uint32_t abundance, uint32_t *__restrict__ bits,
+                                                                     uint64_t *__restrict__ emit_keys, uint64_t emit_cap,
+                                                                     unsigned long long *__restrict__ emit_n)
 {
     __shared__ uint32_t cnt_all[P3_WAVES][CNT_WORDS];
     __shared__ uint32_t bit_all[P3_WAVES][BIT_WORDS];
     __shared__ __attribute__((aligned(8))) uint16_t stage_all[P3_WAVES][STAGE_KEYS + 8];
+    __shared__ uint64_t emit_all[EMIT ? P3_WAVES : 1][EMIT ? EMIT_CAP : 1];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     uint32_t *cnt = cnt_all[wave];
     uint32_t *bmp = bit_all[wave];
     uint16_t *stage = stage_all[wave];
+    uint64_t *ebuf = emit_all[EMIT ? wave : 0];
+    uint32_t ecount = 0; // wave-uniform
+    auto emit_flush = [&]() {
+        if (ecount) {
+            unsigned long long base = 0;
+            if (lane == 0)
+                base = atomicAdd(emit_n, (unsigned long long)ecount);
+            base = __shfl(base, 0);
+            asm volatile("" ::: "memory");
+            for (uint32_t q = lane; q < ecount; q += 64)
+                if (base + q < emit_cap)
+                    emit_keys[base + q] = ebuf[q];
+            asm volatile("" ::: "memory");
+            ecount = 0;
+        }
+    };
     for (uint32_t w = lane; w < CNT_WORDS; w += 64)
         cnt[w] = 0;
     for (uint32_t w = lane; w < BIT_WORDS; w += 64)
@@ -571,9 +596,30 @@ __global__ __launch_bounds__(64 * P3_WAVES) void final_count_kernel(const uint16
             }
             *reinterpret_cast<uint2 *>(dst + 2 * lane) = make_uint2(w0, w1);
             asm volatile("" ::: "memory");
+            if (EMIT && any_bit) {
+                // one hash per lane and turn (slices hold a handful of bits: usually a single turn)
+                uint64_t rem = (uint64_t)w0 | ((uint64_t)w1 << 32);
+                const uint64_t hbase = (g0 + (uint64_t)j) * F_SIZE + 64ull * (uint64_t)lane;
+                for (;;) {
+                    const uint64_t bal = __ballot(rem != 0ull);
+                    if (!bal)
+                        break;
+                    if (ecount + 64u > EMIT_CAP)
+                        emit_flush();
+                    if (rem) {
+                        const uint32_t pos = ecount + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32),
+                                                                                __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+                        ebuf[pos] = hbase + (uint64_t)__builtin_ctzll(rem);
+                        rem &= rem - 1ull;
+                    }
+                    ecount += (uint32_t)__builtin_popcountll(bal);
+                }
+            }
         }
         g0 += (uint64_t)gcount;
     }
+    if (EMIT)
+        emit_flush();
 }
 
 // concatenates, per level-1 bucket, the segments of every batch (only needed for > 1 batch)
@@ -945,6 +991,25 @@ int part_finish_into(brx_counter *c, uint32_t abundance, hipStream_t s, brx_set 
         BRX_TRY(ensure_dev((void **)&st->d_keys_fin, &capb, (total + 64) * 2));
         st->keys_fin_cap = capb;
     }
+    // solid-key list for the probe index: a solid hash was seen more than `abundance` times, so there are at
+    // most total / (abundance + 1) of them; real data is far below that, and a list that turns out too short
+    // is simply not used (the index is then built from the bit vector)
+    const bool emit = index_wanted(c->k);
+    if (emit) {
+        const uint64_t div = abundance + 1u > 8u ? abundance + 1u : 8u;
+        const uint64_t want = total / div + (1ull << 20);
+        if (dst->keylist_cap < want || !dst->d_keylist) {
+            if (dst->d_keylist)
+                (void)hipFree(dst->d_keylist);
+            dst->d_keylist = nullptr;
+            dst->keylist_cap = 0;
+            BRX_HIP(hipMalloc((void **)&dst->d_keylist, want * 8));
+            dst->keylist_cap = want;
+        }
+        if (!dst->d_keylist_n)
+            BRX_HIP(hipMalloc((void **)&dst->d_keylist_n, 8));
+        BRX_HIP(hipMemsetAsync(dst->d_keylist_n, 0, 8, s));
+    }
     const uint64_t *fin_off = nullptr;
     if (pl.nlev == 2) {
         BRX_TRY(run_level<uint16_t>(st, 1, keys1, l1off, pl.nchild[0], total, st->d_keys_fin, s, "part_l2_hist",
@@ -965,9 +1030,15 @@ int part_finish_into(brx_counter *c, uint32_t abundance, hipStream_t s, brx_set 
         const uint64_t nb = pl.nchild[pl.nlev - 1];
         const uint64_t want_waves = nb < (256ull * 16ull * 8ull) ? nb : (256ull * 16ull * 8ull);
         const int grid = (int)((want_waves + P3_WAVES - 1) / P3_WAVES);
-        final_count_kernel<<<grid, 64 * P3_WAVES, 0, s>>>(st->d_keys_fin, fin_off, nb, abundance, dst->d_bits);
+        if (emit)
+            final_count_kernel<true><<<grid, 64 * P3_WAVES, 0, s>>>(st->d_keys_fin, fin_off, nb, abundance, dst->d_bits,
+                                                                   dst->d_keylist, dst->keylist_cap, dst->d_keylist_n);
+        else
+            final_count_kernel<false><<<grid, 64 * P3_WAVES, 0, s>>>(st->d_keys_fin, fin_off, nb, abundance, dst->d_bits,
+                                                                    nullptr, 0, nullptr);
     }
     BRX_HIP(hipGetLastError());
+    dst->keylist_valid = emit;
     return BRX_OK;
 }
 

@@ -428,6 +428,7 @@ int brx_set_insert_batch(brx_set_t *set, const uint8_t *bases, const uint64_t *o
     BRX_TRY(use_device(set->device));
     if (n_reads == 0)
         return BRX_OK;
+    index_invalidate(set);
     uint8_t *d_b = nullptr;
     uint64_t *d_o = nullptr;
     uint64_t bc = 0, oc = 0, tot = 0;
@@ -455,6 +456,7 @@ int brx_set_set(brx_set_t *set, uint64_t forward_kmer, bool value)
     if (!set)
         return BRX_ERR_ARG;
     BRX_TRY(use_device(set->device));
+    index_invalidate(set);
     const uint64_t h = khash(forward_kmer & kmask(set->k), set->k);
     set_bit_kernel<<<1, 1>>>(set->d_bits, h, value ? 1 : 0);
     BRX_HIP(hipDeviceSynchronize());
@@ -555,8 +557,16 @@ void brx_set_free(brx_set_t *set)
 {
     if (!set)
         return;
-    if (set->d_bits && use_device(set->device) == BRX_OK)
-        (void)hipFree(set->d_bits);
+    if (use_device(set->device) == BRX_OK) {
+        if (set->d_bits)
+            (void)hipFree(set->d_bits);
+        if (set->d_lines)
+            (void)hipFree(set->d_lines);
+        if (set->d_keylist)
+            (void)hipFree(set->d_keylist);
+        if (set->d_keylist_n)
+            (void)hipFree(set->d_keylist_n);
+    }
     delete set;
 }
 
@@ -695,6 +705,7 @@ int brx_set_count_finish_into(brx_counter_t *c, uint8_t abundance, void *stream,
         return BRX_ERR_ARG;
     }
     BRX_TRY(use_device(c->device));
+    index_invalidate(dst);
     hipStream_t s = (hipStream_t)stream; // nullptr = the legacy default stream, like any HIP API
     if (c->strategy == BRX_COUNT_SORTED)
         return part_finish_into(c, abundance, s, dst);
@@ -858,6 +869,7 @@ int brx_set_or_keys_device(brx_set_t *set, const uint64_t *d_keys, uint64_t n, v
     BRX_TRY(use_device(set->device));
     if (!n)
         return BRX_OK;
+    index_invalidate(set);
     hipStream_t s = (hipStream_t)stream;
     {
         KernelTimer t("or_keys", s);

@@ -164,6 +164,33 @@ class Pcon(KmerSet):
     def or_keys_device(self, d_keys: int, n: int, stream: Optional[int] = None) -> None:
         _lib.check(_lib.lib().brx_set_or_keys_device(self._h, d_keys, n, stream))
 
+    # ---- probe index (include/brx.h: an HBM-locality copy of the set, no reference counterpart) ----
+    def index_build(self, m: int = 0, log2_lines: int = 0, stream: Optional[int] = None) -> dict:
+        _lib.check(_lib.lib().brx_set_index_build(self._h, m, log2_lines, stream))
+        return self.index_info()
+
+    def index_build_from_keys_device(self, d_keys: int, n: int, m: int = 0, log2_lines: int = 0,
+                                     stream: Optional[int] = None) -> dict:
+        _lib.check(_lib.lib().brx_set_index_build_from_keys_device(self._h, d_keys, n, m, log2_lines, stream))
+        return self.index_info()
+
+    def index_drop(self) -> None:
+        _lib.check(_lib.lib().brx_set_index_drop(self._h))
+
+    def index_info(self) -> dict:
+        v = (C.c_uint64 * 8)()
+        _lib.check(_lib.lib().brx_set_index_info(self._h, v))
+        return {"valid": bool(v[0]), "m": int(v[1]), "log2_lines": int(v[2]), "keys": int(v[3]),
+                "overflow_keys": int(v[4]), "bytes": int(v[5])}
+
+    def get_batch_indexed(self, kmers):
+        """(answers, n_fallback): `get_batch` through the probe index."""
+        ks = np.ascontiguousarray(kmers, dtype=np.uint64)
+        out = np.empty(len(ks), dtype=np.uint8)
+        fb = C.c_uint64(0)
+        _lib.check(_lib.lib().brx_set_get_batch_indexed(self._h, ks.ctypes.data, len(ks), out.ctypes.data, C.byref(fb)))
+        return out.astype(bool), fb.value
+
 
 class Counter:
     """pcon::counter::Counter<u8> as used by `br fasta` (src/main.rs:73-78)."""

@@ -103,6 +103,25 @@ int brx_set_device_bits(const brx_set_t *set, void **d_bits, uint64_t *n_bytes);
 int brx_set_extract_keys_device(const brx_set_t *set, uint64_t first_hash, uint64_t n_hashes, uint64_t *d_out, uint64_t cap,
                                 uint64_t *n_out, void *stream);
 int brx_set_or_keys_device(brx_set_t *set, const uint64_t *d_keys, uint64_t n, void *stream);
+/* ---- probe index: no counterpart in the reference (an HBM-locality copy of the same set) ------
+ * KmerSet::get is one bit of a 2^(2k-1)-bit vector; the k-mers a read walks through hit unrelated
+ * 64-byte lines.  The index stores the solid k-mers a second time in 64-byte lines addressed by the
+ * k-mer's strand-symmetric minimizer, so that neighbouring k-mers of a read share a line.  It is exact
+ * (full keys; a line that overflowed sends the probe back to the bitset) and only changes where
+ * `get` reads.  The correction entry points build it on first use for 15 <= k <= 19 (BRX_INDEX=0
+ * disables); every mutation of the bits through this ABI drops it.  m = minimizer length (odd, <= 15),
+ * log2_lines = table size; 0 = automatic.                                                          */
+int brx_set_index_build(brx_set_t *set, int m, int log2_lines, void *stream);
+/* same, from a device list of the set's bit indices (e.g. the keys just exchanged between ranks)     */
+int brx_set_index_build_from_keys_device(brx_set_t *set, const uint64_t *d_keys, uint64_t n, int m, int log2_lines,
+                                         void *stream);
+int brx_set_index_drop(brx_set_t *set);
+/* info8: [0] valid, [1] m, [2] log2_lines, [3] keys, [4] keys left to the bitset (overflow), [5] bytes */
+int brx_set_index_info(const brx_set_t *set, uint64_t *info8);
+/* brx_set_get_batch answered through the index (+ bitset for overflowed lines); *n_fallback = probes
+ * that needed the bitset                                                                             */
+int brx_set_get_batch_indexed(const brx_set_t *set, const uint64_t *forward_kmers, uint32_t n, uint8_t *out,
+                              uint64_t *n_fallback);
 void brx_set_free(brx_set_t *set);
 
 /* ---- set build by counting: src/main.rs:72-115 -------------------------------------------

@@ -61,9 +61,13 @@ res = {"tag": tag, "calibration": {"random_4B_load_bytes_as_counted": cal_rand,
                                    "stream_fraction_counted": cal_stream}, "bases_per_launch": bases, "kernels": summary}
 with open(os.path.join(here, f"{tag}_pmc_summary.json"), "w") as f:
     json.dump(res, f, indent=1)
-ck = [v for k, v in summary.items() if k.startswith("correct_kernel<16, 0>") or k.startswith("correct_kernel<")]
+# correct_pass = every correct_kernel<G, M> instance (forward G=16 and reverse G=64 launches): launch-weighted mean
+ck = [v for k, v in summary.items() if k.startswith("correct_kernel<")]
 if ck and bases:
+    n_launch = sum(v["launches"] for v in ck)
+    per_launch = sum(v["hbm_bytes_per_launch"] * v["launches"] for v in ck) / n_launch
     with open(os.path.join(here, "traffic_latest.json"), "w") as f:
-        json.dump({"kernel": "correct_pass", "bases_per_launch": bases, "hbm_bytes_per_launch": ck[0]["hbm_bytes_per_launch"],
+        json.dump({"kernel": "correct_pass", "bases_per_launch": bases, "hbm_bytes_per_launch": per_launch,
+                   "launches_averaged": n_launch,
                    "source": f"profiles/{tag}_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"}, f)
-print(json.dumps(res["calibration"]), ck[0] if ck else None)
+print(json.dumps(res["calibration"]), ck)

@@ -1,0 +1,94 @@
+// Feasibility micro-benchmark (not part of the product): probe rate of a LINE-bucketed set layout,
+// where runs of SHARE adjacent lanes (consecutive k-mers of a read sharing a minimizer) read the SAME
+// 64-byte line and every lane reads BYTES of it, against independent 4-byte probes (SHARE=1, BYTES=4).
+// Build: hipcc -O3 --offload-arch=gfx950 tools/line_probe_bench.hip -o tools/line_probe_bench
+// Run  : tools/line_probe_bench [table_MiB=256] [probes_per_thread=64]
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+
+__device__ __forceinline__ uint64_t mix64(uint64_t z)
+{
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+template <int SHARE, int BYTES>
+__global__ __launch_bounds__(256) void line_probe(const uint32_t *__restrict__ t, uint64_t nlines_mask, int iters, uint32_t *sink)
+{
+    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t run = tid / SHARE;
+    uint32_t acc = 0;
+    for (int it = 0; it < iters; it++) {
+        const uint64_t line = mix64(run * 1315423911ull + (uint64_t)it) & nlines_mask;
+        const uint32_t *p = t + (BYTES > 64 ? (line & ~(uint64_t)(BYTES / 64 - 1)) : line) * 16;
+        if (BYTES == 4) {
+            acc ^= p[threadIdx.x & 15];
+        } else {
+            const uint4 *q = (const uint4 *)p;
+#pragma unroll
+            for (int j = 0; j < BYTES / 16; j++) {
+                const uint4 v = q[j];
+                acc ^= v.x ^ v.y ^ v.z ^ v.w;
+            }
+        }
+    }
+    if (acc == 0x12345u)
+        *sink = acc;
+}
+
+template <int SHARE, int BYTES>
+static void run(const uint32_t *d, uint64_t mask, int iters, uint32_t *sink, int blocks)
+{
+    hipEvent_t a, b;
+    CK(hipEventCreate(&a));
+    CK(hipEventCreate(&b));
+    line_probe<SHARE, BYTES><<<blocks, 256>>>(d, mask, iters, sink);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(a));
+    line_probe<SHARE, BYTES><<<blocks, 256>>>(d, mask, iters, sink);
+    CK(hipEventRecord(b));
+    CK(hipEventSynchronize(b));
+    float ms;
+    CK(hipEventElapsedTime(&ms, a, b));
+    const double probes = (double)blocks * 256 * iters;
+    printf("share=%-2d bytes/lane=%-2d blocks=%-5d: %8.3f ms  %7.2f Gprobe/s  %7.2f Gline/s\n", SHARE, BYTES, blocks, ms,
+           probes / ms / 1e6, probes / SHARE / ms / 1e6);
+    fflush(stdout);
+}
+
+int main(int argc, char **argv)
+{
+    const double mib = argc > 1 ? atof(argv[1]) : 256.0;
+    const int iters = argc > 2 ? atoi(argv[2]) : 64;
+    uint64_t nlines = 1;
+    while (nlines * 2 * 64 <= (uint64_t)(mib * (1ull << 20)))
+        nlines *= 2;
+    uint32_t *d, *sink;
+    CK(hipMalloc((void **)&d, nlines * 64));
+    CK(hipMalloc((void **)&sink, 4));
+    CK(hipMemset(d, 1, nlines * 64));
+    printf("table %.1f MiB (%llu lines)\n", nlines * 64.0 / (1 << 20), (unsigned long long)nlines);
+    const int blocks = 8192;
+    run<1, 4>(d, nlines - 1, iters, sink, blocks);
+    run<1, 16>(d, nlines - 1, iters, sink, blocks);
+    run<1, 64>(d, nlines - 1, iters, sink, blocks);
+    run<2, 64>(d, nlines - 1, iters, sink, blocks);
+    run<4, 4>(d, nlines - 1, iters, sink, blocks);
+    run<4, 16>(d, nlines - 1, iters, sink, blocks);
+    run<4, 32>(d, nlines - 1, iters, sink, blocks);
+    run<4, 64>(d, nlines - 1, iters, sink, blocks);
+    run<1, 128>(d, nlines - 1, iters, sink, blocks);
+    run<4, 128>(d, nlines - 1, iters, sink, blocks);
+    run<1, 256>(d, nlines - 1, iters, sink, blocks);
+    run<4, 256>(d, nlines - 1, iters, sink, blocks);
+    run<8, 16>(d, nlines - 1, iters, sink, blocks);
+    run<8, 64>(d, nlines - 1, iters, sink, blocks);
+    run<16, 64>(d, nlines - 1, iters, sink, blocks);
+    return 0;
+}
