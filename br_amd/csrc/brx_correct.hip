@@ -64,8 +64,7 @@ struct PassParams {
     uint64_t *path_k;
     uint32_t maxpath;
     // greedy (greedy.rs): max_search and the per-group LDS carve-up for the alignment
-    uint32_t flags;       // tuning switches for A/B runs (BRX_TUNE): 1 no look-ahead reuse, 2 four ALTS probes, 4 unstaged SCEN,
-                          // 16 state scheduler (one state per round; measured slower, kept for experiments)
+    uint32_t flags;       // tuning switches for A/B runs (BRX_TUNE): 1 no look-ahead reuse, 2 four ALTS probes, 4 unstaged SCEN
     int max_search;
     uint32_t g_dim;       // max (m+1), (n+1) of the DP = k + max_search + 2
     uint32_t g_lds_bytes; // bytes of dynamic LDS per group
@@ -82,18 +81,7 @@ __device__ __forceinline__ bool probe(const uint32_t *__restrict__ bits, uint64_
     return (bits[h >> 5] >> (h & 31u)) & 1u;
 }
 
-enum { ST_INIT = 0, ST_SCAN, ST_ERRLEN, ST_ALTS, ST_SCEN, ST_MORE, ST_WALK, ST_T1, ST_TSCORE, ST_TMORE, ST_GFOLLOW, ST_GVALID, ST_COUNT };
-constexpr uint32_t AGE_LIMIT = 6;
-
-// states a kernel instance of method M can be in (prunes the scheduler's per-state ballots)
-template <int M>
-__device__ constexpr bool state_reachable(int x)
-{
-    const bool errlen = (M == BRX_GRAPH || M == BRX_GAP_SIZE), one = (M == BRX_ONE || M == BRX_GAP_SIZE);
-    return x == ST_INIT || x == ST_SCAN || x == ST_ALTS || (x == ST_ERRLEN && errlen) || ((x == ST_SCEN || x == ST_MORE) && one) ||
-           (x == ST_WALK && errlen) || ((x == ST_T1 || x == ST_TSCORE || x == ST_TMORE) && M == BRX_TWO) ||
-           ((x == ST_GFOLLOW || x == ST_GVALID) && M == BRX_GREEDY);
-}
+enum { ST_INIT = 0, ST_SCAN, ST_ERRLEN, ST_ALTS, ST_SCEN, ST_MORE, ST_WALK, ST_T1, ST_TSCORE, ST_TMORE, ST_GFOLLOW, ST_GVALID };
 enum { MODE_ONE = 0, MODE_GRAPH = 1, MODE_INSSUB = 2, MODE_TWO = 3 };
 
 // ---- ScenarioTwo (src/correct/exist/two.rs:34-328), ids in declaration order ---------------------
@@ -487,39 +475,7 @@ __global__ __launch_bounds__(256, (M == BRX_ONE ? 6 : 1)) void correct_kernel(Pa
 
     fetch();
 
-    uint32_t wait = 0; // rounds this group has been passed over by the state scheduler
-    for (;;) {
-        // ---------------- phase 0: which state runs this round -------------------------------
-        // The groups of a wave sit in different states, and code of a state costs the wave the same
-        // whether one group or all of them execute it.  So a round serves ONE state: the one most
-        // groups are in (a group passed over AGE_LIMIT times in a row goes first).  Groups in other
-        // states idle for the round; they pile up in their state and are served together later.
-        const bool leader = have && gl == 0;
-        const uint64_t lead = __ballot(leader);
-        if (!lead)
-            break;
-        int run_st = -1;
-        if (p.flags & 16u) {
-            const uint64_t starving = __ballot(leader && wait >= AGE_LIMIT);
-            if (starving) {
-                run_st = __shfl(st, __builtin_ctzll(starving));
-            } else {
-                int best = 0;
-#pragma unroll
-                for (int x = 0; x < ST_COUNT; x++) {
-                    if (!state_reachable<M>(x))
-                        continue;
-                    const int cnt = __builtin_popcountll(__ballot(leader && st == x));
-                    if (cnt > best) {
-                        best = cnt;
-                        run_st = x;
-                    }
-                }
-            }
-        }
-        const bool act = have && (run_st < 0 || st == run_st);
-        wait = (have && !act) ? wait + 1u : 0u;
-
+    while (__any(have)) {
         bool do_probe = false;
         uint64_t pk = 0;
         uint8_t ch = 0;
@@ -527,7 +483,7 @@ __global__ __launch_bounds__(256, (M == BRX_ONE ? 6 : 1)) void correct_kernel(Pa
         bool sc_active = false;
 
         // ---------------- phase 1: choose this round's probe --------------------------------
-        if (act) {
+        if (have) {
             n_rounds += (gl == 0);
             if (st == ST_INIT) {
                 if (n < (uint32_t)k) {
@@ -693,11 +649,9 @@ __global__ __launch_bounds__(256, (M == BRX_ONE ? 6 : 1)) void correct_kernel(Pa
                 }
             }
             retry = ((__ballot(unres) >> gshift) & GM) != 0ull;
-            if (act) { // a group the scheduler passed over keeps its pending re-run
-                slow = retry;
-                was_unres = unres;
-                kept_sol = sol;
-            }
+            slow = retry;
+            was_unres = unres;
+            kept_sol = sol;
         } else if (do_probe) {
             sol = probe(p.bits, pk, k);
             n_probes++;
@@ -706,7 +660,7 @@ __global__ __launch_bounds__(256, (M == BRX_ONE ? 6 : 1)) void correct_kernel(Pa
         const uint64_t gmask = (ball >> gshift) & GM;
 
         // ---------------- phase 3: group-uniform transitions ----------------------------------
-        if (act && !retry) {
+        if (have && !retry) {
             bool fail = false;   // correct_error returned None
             int apply_s = -1;    // One scenario to apply
             int apply_t = -1;    // Two scenario to apply
@@ -1427,7 +1381,7 @@ int brx_chain_correct_batch_device(brx_chain_t *ch, const uint8_t *d_bases, cons
     const int n_dirs = ch->two_side ? 1 : 2;
     const int n_methods = (int)ch->methods.size();
     uint64_t stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    const int G = group_width(false, idx.lines != nullptr);
+    const int G = group_width(false, idx.lines != nullptr); // forward width (8 exists for One only, else 16)
     bool needs_path = false;
     for (int m = 0; m < n_methods; m++)
         needs_path |= (ch->methods[m].method == BRX_GRAPH || ch->methods[m].method == BRX_GAP_SIZE ||
@@ -1466,7 +1420,12 @@ int brx_chain_correct_batch_device(brx_chain_t *ch, const uint8_t *d_bases, cons
             for (int m = 0; m < n_methods; m++) {
                 PassParams p;
                 p.bits = ch->set->d_bits;
-                p.idx = idx;
+                // the index pays where whole groups probe neighbouring k-mers: One's passes and the (nearly
+                // trigger-free) reverse scans.  Walks probe 4 successors of one k-mer per round: measured
+                // 10-15 % slower through the index (Graph, GapSize forward), Greedy 78 % slower.
+                const int mth = ch->methods[m].method;
+                const bool use_idx = mth == BRX_ONE || (dir == 1 && mth != BRX_GREEDY);
+                p.idx = use_idx ? idx : IdxView{nullptr, 0, 0, 0};
                 p.k = k;
                 p.c = ch->methods[m].confirm;
                 p.n_reads = n_reads;
@@ -1482,7 +1441,10 @@ int brx_chain_correct_batch_device(brx_chain_t *ch, const uint8_t *d_bases, cons
                 p.path_k = ch->d_path;
                 p.maxpath = maxpath;
                 BRX_HIP(hipMemsetAsync(ch->d_ctrl + CTL_WORK, 0, 8, s));
-                BRX_TRY(launch_pass(p, ch->methods[m], dir ? group_width(true) : G, s));
+                int gw = dir ? group_width(true) : G;
+                if (gw < 16 && mth != BRX_ONE)
+                    gw = 16; // only One has an 8-lane instance
+                BRX_TRY(launch_pass(p, ch->methods[m], gw, s));
                 cur = ch->d_stage[pp];
                 cur_lens = ch->d_lens[pp];
                 cur_staged = 1;

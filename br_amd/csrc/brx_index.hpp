@@ -44,7 +44,7 @@ __device__ __forceinline__ uint32_t minimizer_hash_w(uint64_t fwd, uint64_t rc, 
         const uint32_t f = __builtin_amdgcn_alignbit(fhi, flo, 2 * j) & mm;
         const uint32_t r = __builtin_amdgcn_alignbit(rhi, rlo, 2 * (W - 1 - j)) & mm;
         const uint32_t c = f < r ? f : r;
-        const uint32_t h = c * 0x9E3779B1u;
+        const uint32_t h = c * 0x9E3779B1u; // (a full-rate xor+rotate scramble measured no faster: the kernel waits on memory)
         best = h < best ? h : best;
     }
     return best;
