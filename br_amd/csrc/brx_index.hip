@@ -231,6 +231,25 @@ int brx_set_index_build_from_keys_device(brx_set_t *set, const uint64_t *d_keys,
     return index_build_from_keys(set, d_keys, n, m, log2_lines, (hipStream_t)stream);
 }
 
+int brx_set_keylist_device(const brx_set_t *set, void **d_keys, uint64_t *n, void *stream)
+{
+    if (!set || !d_keys || !n)
+        return BRX_ERR_ARG;
+    *d_keys = nullptr;
+    *n = 0;
+    if (!set->keylist_valid)
+        return BRX_OK;
+    BRX_TRY(use_device(set->device));
+    unsigned long long nl = 0;
+    BRX_HIP(hipMemcpyAsync(&nl, set->d_keylist_n, 8, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    BRX_HIP(hipStreamSynchronize((hipStream_t)stream));
+    if (nl > set->keylist_cap)
+        return BRX_OK; // truncated list: treat as absent
+    *d_keys = set->d_keylist;
+    *n = nl;
+    return BRX_OK;
+}
+
 int brx_set_index_drop(brx_set_t *set)
 {
     if (!set)
@@ -251,6 +270,8 @@ int brx_set_index_info(const brx_set_t *set, uint64_t *info8)
     for (int i = 0; i < 8; i++)
         info8[i] = 0;
     info8[0] = set->idx_valid ? 1 : 0;
+    info8[6] = index_wanted(set->k) ? 1 : 0;
+    info8[7] = set->keylist_valid ? 1 : 0;
     if (set->idx_valid) {
         info8[1] = set->idx_m;
         info8[2] = set->idx_log_lines;

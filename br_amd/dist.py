@@ -193,6 +193,9 @@ def exchange_partitioned(engine, abundance: int, world: int, rank: int) -> None:
     for s in range(world):
         if s != rank and counts_h[s]:
             engine.or_keys(gathered[s][:counts_h[s]])
+    if hasattr(engine, "all_keys"):
+        # every solid k-mer of the job is in hand as a list: hand it to the set (probe index without a scan)
+        engine.all_keys([solid] + [gathered[s][:counts_h[s]] for s in range(world) if s != rank and counts_h[s]])
 
 
 class GpuPartitionedEngine:
@@ -227,6 +230,11 @@ class GpuPartitionedEngine:
         self.counter.finish_into(abundance, self.solid, self.stream)
 
     def extract(self, first_hash: int, n_hashes: int) -> torch.Tensor:
+        # the partitioned finish leaves the list of solid hashes with the set (only owned buckets were counted)
+        kl = self.solid.keylist_device(self.stream)
+        if kl is not None:
+            ptr, n = kl
+            return device_view(ptr, max(n, 1) * 8).view(torch.int64)[:n].clone()
         # everything outside the owned range is still zero, so the whole-set popcount sizes the list
         torch.cuda.current_stream().synchronize()
         cap = self.solid.popcount() + 64
@@ -238,6 +246,12 @@ class GpuPartitionedEngine:
         keys = keys.contiguous()
         self._keep.append(keys)
         self.solid.or_keys_device(keys.data_ptr(), keys.numel(), self.stream)
+
+    def all_keys(self, lists) -> None:
+        if self.solid.index_info()["wanted"]:
+            keys = torch.cat(lists) if len(lists) > 1 else lists[0]
+            self._keep.append(keys)
+            self.solid.index_build_from_keys_device(keys.data_ptr(), keys.numel(), 0, 0, self.stream)
 
     def release(self) -> None:
         """drop the references that kept received segments alive (after the set is final)"""

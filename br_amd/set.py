@@ -174,6 +174,12 @@ class Pcon(KmerSet):
         _lib.check(_lib.lib().brx_set_index_build_from_keys_device(self._h, d_keys, n, m, log2_lines, stream))
         return self.index_info()
 
+    def keylist_device(self, stream: Optional[int] = None):
+        """(device pointer, n) of the solid-hash list a partitioned finish left with the set, or None"""
+        ptr, n = C.c_void_p(), C.c_uint64(0)
+        _lib.check(_lib.lib().brx_set_keylist_device(self._h, C.byref(ptr), C.byref(n), stream))
+        return (ptr.value, n.value) if ptr.value else None
+
     def index_drop(self) -> None:
         _lib.check(_lib.lib().brx_set_index_drop(self._h))
 
@@ -181,7 +187,7 @@ class Pcon(KmerSet):
         v = (C.c_uint64 * 8)()
         _lib.check(_lib.lib().brx_set_index_info(self._h, v))
         return {"valid": bool(v[0]), "m": int(v[1]), "log2_lines": int(v[2]), "keys": int(v[3]),
-                "overflow_keys": int(v[4]), "bytes": int(v[5])}
+                "overflow_keys": int(v[4]), "bytes": int(v[5]), "wanted": bool(v[6]), "keylist": bool(v[7])}
 
     def get_batch_indexed(self, kmers):
         """(answers, n_fallback): `get_batch` through the probe index."""

@@ -116,7 +116,12 @@ int brx_set_index_build(brx_set_t *set, int m, int log2_lines, void *stream);
 int brx_set_index_build_from_keys_device(brx_set_t *set, const uint64_t *d_keys, uint64_t n, int m, int log2_lines,
                                          void *stream);
 int brx_set_index_drop(brx_set_t *set);
-/* info8: [0] valid, [1] m, [2] log2_lines, [3] keys, [4] keys left to the bitset (overflow), [5] bytes */
+/* the list of the set's bit indices (any order) when the builder produced one on the side (partitioned
+ * brx_set_count_finish[_into]); *d_keys == NULL when there is none.  Valid until the set is mutated.
+ * Lets the multi-GPU exchange ship the solid k-mers of a rank's range without scanning the bit vector.  */
+int brx_set_keylist_device(const brx_set_t *set, void **d_keys, uint64_t *n, void *stream);
+/* info8: [0] valid, [1] m, [2] log2_lines, [3] keys, [4] keys left to the bitset (overflow), [5] bytes,
+ * [6] the correction entry points would use an index for this k, [7] a key list is attached          */
 int brx_set_index_info(const brx_set_t *set, uint64_t *info8);
 /* brx_set_get_batch answered through the index (+ bitset for overflowed lines); *n_fallback = probes
  * that needed the bitset                                                                             */
