@@ -1178,7 +1178,9 @@ int ensure(void **p, uint64_t *cap, uint64_t need)
     return BRX_OK;
 }
 
-int group_width(bool reverse_pass = false, bool indexed = false)
+constexpr uint64_t RESIDENT_LANES = 256ull * 4ull * 6ull * 64ull; // CUs x SIMDs x waves x lanes at occupancy 6
+
+int group_width(bool reverse_pass = false, bool indexed = false, uint32_t n_reads = 0xffffffffu)
 {
     // lanes per read; BRX_GROUP / BRX_GROUP_REV override (read on every launch so tests can sweep them).
     // The reverse pass of run_correction (src/lib.rs:48-55) sees almost only non-solid k-mers and hardly
@@ -1189,7 +1191,13 @@ int group_width(bool reverse_pass = false, bool indexed = false)
     // measured (tools/ab_correct.py): bitset probes 16/64 (+3 % over 16/16); with the probe index the shared
     // probe code is the larger part of a round and 8 groups per wave amortise it better: 8/64 (+5 % over 16/64)
     const int dflt = reverse_pass ? 64 : (indexed ? 8 : 16);
-    const int g = e ? atoi(e) : dflt;
+    int g = e ? atoi(e) : dflt;
+    if (!e) {
+        // small batches (the reference's 8192 records): with fewer reads than resident groups the GPU idles and
+        // the time is one read's chain of rounds -- wider groups advance further per round
+        while (g < 64 && (uint64_t)n_reads * (uint64_t)g * 2u <= RESIDENT_LANES)
+            g *= 2;
+    }
     return (g == 8 || g == 16 || g == 32 || g == 64) ? g : dflt;
 }
 
@@ -1381,7 +1389,7 @@ int brx_chain_correct_batch_device(brx_chain_t *ch, const uint8_t *d_bases, cons
     const int n_dirs = ch->two_side ? 1 : 2;
     const int n_methods = (int)ch->methods.size();
     uint64_t stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    const int G = group_width(false, idx.lines != nullptr); // forward width (8 exists for One only, else 16)
+    const int G = group_width(false, idx.lines != nullptr, n_reads); // forward width (8 exists for One only, else 16)
     bool needs_path = false;
     for (int m = 0; m < n_methods; m++)
         needs_path |= (ch->methods[m].method == BRX_GRAPH || ch->methods[m].method == BRX_GAP_SIZE ||
@@ -1441,7 +1449,7 @@ int brx_chain_correct_batch_device(brx_chain_t *ch, const uint8_t *d_bases, cons
                 p.path_k = ch->d_path;
                 p.maxpath = maxpath;
                 BRX_HIP(hipMemsetAsync(ch->d_ctrl + CTL_WORK, 0, 8, s));
-                int gw = dir ? group_width(true) : G;
+                int gw = dir ? group_width(true, false, n_reads) : G;
                 if (gw < 16 && mth != BRX_ONE)
                     gw = 16; // only One has an 8-lane instance
                 BRX_TRY(launch_pass(p, ch->methods[m], gw, s));
