@@ -35,6 +35,7 @@ def open_input(path: str) -> BinaryIO:
     """niffler::get_reader: sniff gz / bz2 / xz by magic bytes (src/cli.rs:209,269,404,415)."""
     raw = open(path, "rb")
     head = raw.peek(6)[:6] if hasattr(raw, "peek") else b""
+    # (peek does not move the logical position: a plain file can still be handed to the native pipeline as a descriptor)
     if head[:2] == b"\x1f\x8b":
         return gzip.open(raw, "rb")
     if head[:3] == b"BZh":
@@ -114,17 +115,16 @@ def build_set(args) -> Pcon:
     if args.subcommand == "fasta":
         k = fasta_kmer_size(args.kmer_size)
         if args.abundance is not None:
-            return Pcon.from_count(_records(args.sub_inputs), k, args.abundance, dev)
+            cnt = Counter(k, dev)
+            for path in args.sub_inputs:
+                with open_input(path) as f:
+                    cnt.count_fasta(f)
+            return cnt.finish(args.abundance)
         if args.abundance_selection == "first-minimum":
             cnt = Counter(k, dev, _lib.COUNT_DENSE)  # the spectrum needs the u8 table
-            chunk = []
-            for seq in _records(args.sub_inputs):
-                chunk.append(seq)
-                if len(chunk) == 8192:
-                    cnt.add_reads(chunk)
-                    chunk = []
-            if chunk:
-                cnt.add_reads(chunk)
+            for path in args.sub_inputs:
+                with open_input(path) as f:
+                    cnt.count_fasta(f)
             thr = first_minimum(cnt.spectrum())
             if thr is None:
                 raise SystemExit("Error: Can't compute minimal abundance")          # error.rs ComputeAbundanceThreshold

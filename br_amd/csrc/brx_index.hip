@@ -88,7 +88,7 @@ int index_auto_m(int k, uint64_t n_keys)
     return m < 3 ? 3 : m;
 }
 
-int index_build_from_keys(brx_set *set, const uint64_t *d_keys, uint64_t n, int m, int log_lines, hipStream_t s)
+static int index_build_locked(brx_set *set, const uint64_t *d_keys, uint64_t n, int m, int log_lines, hipStream_t s)
 {
     const int k = set->k;
     if (!(k & 1) || k < 5 || k > 31) {
@@ -117,7 +117,6 @@ int index_build_from_keys(brx_set *set, const uint64_t *d_keys, uint64_t n, int 
         set_error("probe index: log2(lines)=%d out of range 4..30", log_lines);
         return BRX_ERR_ARG;
     }
-    std::lock_guard<std::mutex> g(set->idx_mu);
     set->idx_valid = false;
     const uint64_t n_lines = 1ull << log_lines;
     if (set->lines_alloc < n_lines) {
@@ -166,10 +165,21 @@ int index_build_from_keys(brx_set *set, const uint64_t *d_keys, uint64_t n, int 
     return BRX_OK;
 }
 
+int index_build_from_keys(brx_set *set, const uint64_t *d_keys, uint64_t n, int m, int log_lines, hipStream_t s)
+{
+    std::lock_guard<std::mutex> g(set->idx_mu);
+    return index_build_locked(set, d_keys, n, m, log_lines, s);
+}
+
 int index_ensure(const brx_set *cset, hipStream_t s)
 {
     brx_set *set = const_cast<brx_set *>(cset);
-    if (set->idx_valid || set->idx_declined || !index_wanted(set->k))
+    if (!index_wanted(set->k))
+        return BRX_OK;
+    // several chains may share the set (one per host thread): exactly one of them builds, the others wait
+    // here and find the index valid -- a second build would wipe lines the first chain's kernels are reading
+    std::lock_guard<std::mutex> g(set->idx_mu);
+    if (set->idx_valid || set->idx_declined)
         return BRX_OK;
     BRX_TRY(use_device(set->device));
     uint64_t n = 0;
@@ -191,13 +201,13 @@ int index_ensure(const brx_set *cset, hipStream_t s)
         return BRX_OK;
     }
     if (listed)
-        return index_build_from_keys(set, set->d_keylist, n, 0, 0, s);
+        return index_build_locked(set, set->d_keylist, n, 0, 0, s);
     uint64_t *d_keys = nullptr;
     BRX_HIP(hipMalloc((void **)&d_keys, (n ? n : 1) * 8));
     uint64_t got = 0;
     int st = brx_set_extract_keys_device(set, 0, set->nwords * 32, d_keys, n, &got, s);
     if (st == BRX_OK)
-        st = index_build_from_keys(set, d_keys, got, 0, 0, s);
+        st = index_build_locked(set, d_keys, got, 0, 0, s);
     (void)hipFree(d_keys);
     return st;
 }

@@ -1,0 +1,686 @@
+// Host pipeline of run_correction (src/lib.rs:22-139) and of count_fasta (src/main.rs:72-78) over file
+// descriptors: FASTA parse -> pinned batch -> H2D -> kernels -> D2H -> FASTA format -> write, the three stages
+// on their own threads so that parsing, the GPU and formatting of consecutive batches overlap.
+//
+// FASTA conventions = noodles::fasta::{Reader, Writer} as the reference uses them (src/lib.rs:30-31,57-60,
+// 80-81,123-131; noodles-fasta 0.38, not vendored, UNPINNED by the reference's tests), the same rules as
+// br_amd/fasta.py (tests compare the two byte for byte):
+//   reader  '>' definition: name = up to the first ASCII whitespace, description = the rest, trimmed;
+//           sequence = the following lines with their line ends (\r, \n) removed; a malformed record ends
+//           the stream silently (`while let Some(Ok(record))`, src/lib.rs:35), records before it are kept.
+//   writer  '>name[ description]\n', then the sequence wrapped at 80 columns.
+// Batches are larger than the reference's 8192 records (reads are independent units and the output keeps
+// the input order, so the batch size cannot change a byte); they are what fills the GPU.
+#include "brx_internal.hpp"
+
+#include <condition_variable>
+#include <deque>
+#include <thread>
+#include <chrono>
+#include <errno.h>
+#include <string.h>
+#include <unistd.h>
+
+using namespace brx;
+
+namespace {
+
+constexpr size_t LINE_BASES = 80;          // noodles fasta::Writer default line_base_count
+constexpr size_t READ_CHUNK = 8u << 20;    // bytes per read() call
+constexpr uint64_t BATCH_BASES = 128ull << 20;
+constexpr int N_SLOTS = 5;
+
+inline bool is_ws(unsigned char c) { return c == ' ' || c == '\t' || c == '\n' || c == '\r' || c == '\v' || c == '\f'; }
+
+double now_s()
+{
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// growable pinned host buffer (hipHostMalloc: H2D / D2H at link speed, async capable)
+struct Pinned {
+    uint8_t *p = nullptr;
+    uint64_t cap = 0;
+    int reserve(uint64_t need, uint64_t keep)
+    {
+        if (need <= cap)
+            return BRX_OK;
+        uint64_t want = cap ? cap : (1u << 20);
+        while (want < need)
+            want += want / 2 + (1u << 20);
+        uint8_t *q = nullptr;
+        hipError_t e = hipHostMalloc((void **)&q, want, hipHostMallocDefault);
+        if (e != hipSuccess) {
+            set_error("hipHostMalloc(%llu B): %s", (unsigned long long)want, hipGetErrorString(e));
+            return BRX_ERR_NOMEM;
+        }
+        if (p) {
+            if (keep)
+                memcpy(q, p, keep);
+            (void)hipHostFree(p);
+        }
+        p = q;
+        cap = want;
+        return BRX_OK;
+    }
+    ~Pinned()
+    {
+        if (p)
+            (void)hipHostFree(p);
+    }
+};
+
+struct Batch {
+    uint64_t seq = 0;             // position in the stream (the writer emits in this order)
+    Pinned bases;                 // concatenated sequences
+    std::vector<uint64_t> offsets; // n + 1
+    std::string defs;             // re-emitted definition lines, concatenated
+    std::vector<uint32_t> def_end; // end offset of record r's definition in `defs`
+    uint64_t total = 0;
+    Pinned out;                   // corrected bases
+    std::vector<uint64_t> out_offsets;
+    bool last = false;
+    void clear()
+    {
+        offsets.assign(1, 0);
+        defs.clear();
+        def_end.clear();
+        total = 0;
+        last = false;
+    }
+    uint32_t n() const { return (uint32_t)def_end.size(); }
+};
+
+template <class T>
+class Queue {
+  public:
+    void push(T v)
+    {
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            q_.push_back(v);
+        }
+        cv_.notify_all();
+    }
+    // false when the queue was closed and is empty
+    bool pop(T &v)
+    {
+        std::unique_lock<std::mutex> g(mu_);
+        cv_.wait(g, [&] { return !q_.empty() || closed_; });
+        if (q_.empty())
+            return false;
+        v = q_.front();
+        q_.pop_front();
+        return true;
+    }
+    void close()
+    {
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            closed_ = true;
+        }
+        cv_.notify_all();
+    }
+
+  private:
+    std::mutex mu_;
+    std::condition_variable cv_;
+    std::deque<T> q_;
+    bool closed_ = false;
+};
+
+// ---- FASTA reader: whole lines out of a growing buffer -------------------------------------------
+class LineReader {
+  public:
+    explicit LineReader(int fd) : fd_(fd) { buf_.resize(READ_CHUNK * 2); }
+    // next line without its trailing run of \r / \n (python's rstrip(b"\r\n")); false at end of input
+    bool next(const char *&line, size_t &len)
+    {
+        for (;;) {
+            const char *nl = (const char *)memchr(buf_.data() + pos_, '\n', end_ - pos_);
+            if (nl) {
+                line = buf_.data() + pos_;
+                len = (size_t)(nl - line);
+                pos_ = (size_t)(nl - buf_.data()) + 1;
+                while (len && (line[len - 1] == '\r' || line[len - 1] == '\n'))
+                    len--;
+                return true;
+            }
+            if (eof_) {
+                if (pos_ == end_)
+                    return false;
+                line = buf_.data() + pos_;
+                len = end_ - pos_;
+                pos_ = end_;
+                while (len && (line[len - 1] == '\r' || line[len - 1] == '\n'))
+                    len--;
+                return true;
+            }
+            // no complete line in the buffer: compact, grow if the line is longer than the buffer, read more
+            if (pos_) {
+                memmove(buf_.data(), buf_.data() + pos_, end_ - pos_);
+                end_ -= pos_;
+                pos_ = 0;
+            }
+            if (buf_.size() - end_ < READ_CHUNK)
+                buf_.resize(buf_.size() * 2);
+            ssize_t r;
+            do {
+                r = ::read(fd_, buf_.data() + end_, READ_CHUNK);
+            } while (r < 0 && errno == EINTR);
+            if (r < 0) {
+                err_ = errno;
+                eof_ = true;
+            } else if (r == 0) {
+                eof_ = true;
+            } else {
+                end_ += (size_t)r;
+            }
+        }
+    }
+    int error() const { return err_; }
+
+  private:
+    int fd_;
+    std::vector<char> buf_;
+    size_t pos_ = 0, end_ = 0;
+    bool eof_ = false;
+    int err_ = 0;
+};
+
+// fills batches from the stream; one record is never split between batches
+class FastaBatcher {
+  public:
+    FastaBatcher(int fd, uint32_t max_records) : lr_(fd), max_records_(max_records ? max_records : 16384u) {}
+    // BRX_OK; b.last is set when the stream ended (a batch may be empty then)
+    int fill(Batch &b)
+    {
+        b.clear();
+        if (done_) {
+            b.last = true;
+            return BRX_OK;
+        }
+        for (;;) {
+            if (have_def_) { // definition read while closing the previous record
+                if (!open_record(b))
+                    break;
+                have_def_ = false;
+            }
+            const char *line;
+            size_t len;
+            if (!lr_.next(line, len)) {
+                close_record(b);
+                done_ = true;
+                break;
+            }
+            if (len && line[0] == '>') {
+                close_record(b);
+                if (!parse_def(line + 1, len - 1)) { // missing name: the stream ends here (src/lib.rs:35)
+                    done_ = true;
+                    break;
+                }
+                have_def_ = true;
+                if (b.n() >= max_records_ || b.total >= BATCH_BASES)
+                    break; // batch full: the pending definition opens the next one
+                continue;
+            }
+            if (!in_record_) { // data before the first definition: parse error
+                done_ = true;
+                break;
+            }
+            if (b.total + len + 64 > b.bases.cap) // one allocation per slot in the common case: a full batch + one long read
+                BRX_TRY(b.bases.reserve(b.total + len + 64 > BATCH_BASES + (32ull << 20) ? b.total + len + 64 : BATCH_BASES + (32ull << 20),
+                                        b.total));
+            memcpy(b.bases.p + b.total, line, len);
+            b.total += len;
+        }
+        if (lr_.error()) {
+            set_error("read: %s", strerror(lr_.error()));
+            return BRX_ERR_ARG;
+        }
+        b.last = done_;
+        return BRX_OK;
+    }
+
+  private:
+    bool parse_def(const char *body, size_t len)
+    {
+        if (len == 0 || is_ws((unsigned char)body[0]))
+            return false;
+        size_t i = 0;
+        while (i < len && !is_ws((unsigned char)body[i]))
+            i++;
+        def_.assign(body, i);
+        size_t j = i;
+        while (j < len && is_ws((unsigned char)body[j]))
+            j++;
+        size_t e = len;
+        while (e > j && is_ws((unsigned char)body[e - 1]))
+            e--;
+        if (e > j) {
+            def_.push_back(' ');
+            def_.append(body + j, e - j);
+        }
+        return true;
+    }
+    bool open_record(Batch &b)
+    {
+        b.defs += def_;
+        in_record_ = true;
+        cur_open_ = true;
+        return true;
+    }
+    void close_record(Batch &b)
+    {
+        if (cur_open_) {
+            b.def_end.push_back((uint32_t)b.defs.size());
+            b.offsets.push_back(b.total);
+            cur_open_ = false;
+        }
+    }
+    LineReader lr_;
+    uint32_t max_records_;
+    std::string def_;
+    bool have_def_ = false, in_record_ = false, cur_open_ = false, done_ = false;
+};
+
+int write_all(int fd, const char *p, size_t n)
+{
+    while (n) {
+        ssize_t w = ::write(fd, p, n);
+        if (w < 0) {
+            if (errno == EINTR)
+                continue;
+            set_error("write: %s", strerror(errno));
+            return BRX_ERR_ARG;
+        }
+        p += w;
+        n -= (size_t)w;
+    }
+    return BRX_OK;
+}
+
+struct Shared {
+    std::mutex mu;
+    int status = BRX_OK;
+    std::string message;
+    void fail(int st)
+    {
+        std::lock_guard<std::mutex> g(mu);
+        if (status == BRX_OK) {
+            status = st;
+            message = brx_last_error();
+        }
+    }
+    bool failed()
+    {
+        std::lock_guard<std::mutex> g(mu);
+        return status != BRX_OK;
+    }
+};
+
+// device-side buffers of one GPU worker
+struct DevBufs {
+    uint8_t *d_in = nullptr, *d_out = nullptr;
+    uint64_t *d_off = nullptr, *d_out_off = nullptr;
+    uint64_t in_cap = 0, out_cap = 0, off_cap = 0;
+    int ensure(uint64_t bases, uint32_t n)
+    {
+        if (bases + 64 > in_cap) {
+            if (d_in)
+                (void)hipFree(d_in);
+            d_in = nullptr;
+            in_cap = bases + bases / 8 + 4096;
+            BRX_HIP(hipMalloc((void **)&d_in, in_cap));
+        }
+        const uint64_t want_out = bases + bases / 16 + 4096;
+        if (want_out > out_cap) {
+            if (d_out)
+                (void)hipFree(d_out);
+            d_out = nullptr;
+            out_cap = want_out + want_out / 8;
+            BRX_HIP(hipMalloc((void **)&d_out, out_cap));
+        }
+        if ((uint64_t)n + 1 > off_cap) {
+            if (d_off)
+                (void)hipFree(d_off);
+            if (d_out_off)
+                (void)hipFree(d_out_off);
+            d_off = d_out_off = nullptr;
+            off_cap = (uint64_t)n + n / 8 + 64;
+            BRX_HIP(hipMalloc((void **)&d_off, off_cap * 8));
+            BRX_HIP(hipMalloc((void **)&d_out_off, off_cap * 8));
+        }
+        return BRX_OK;
+    }
+    ~DevBufs()
+    {
+        if (d_in)
+            (void)hipFree(d_in);
+        if (d_out)
+            (void)hipFree(d_out);
+        if (d_off)
+            (void)hipFree(d_off);
+        if (d_out_off)
+            (void)hipFree(d_out_off);
+    }
+};
+
+int correct_one_batch(brx_chain_t *chain, DevBufs &dv, hipStream_t s, Batch &b)
+{
+    const uint32_t n = b.n();
+    b.out_offsets.assign((size_t)n + 1, 0);
+    if (n == 0)
+        return BRX_OK;
+    BRX_TRY(dv.ensure(b.total, n));
+    if (b.total)
+        BRX_HIP(hipMemcpyAsync(dv.d_in, b.bases.p, b.total, hipMemcpyHostToDevice, s));
+    BRX_HIP(hipMemcpyAsync(dv.d_off, b.offsets.data(), ((size_t)n + 1) * 8, hipMemcpyHostToDevice, s));
+    uint64_t out_total = 0;
+    int st = brx_chain_correct_batch_device(chain, dv.d_in, dv.d_off, n, b.total, dv.d_out, dv.out_cap, dv.d_out_off,
+                                            &out_total, s);
+    if (st == BRX_ERR_OVERFLOW && out_total > dv.out_cap) { // corrections grew the batch beyond the estimate
+        (void)hipFree(dv.d_out);
+        dv.d_out = nullptr;
+        dv.out_cap = out_total + out_total / 16 + 4096;
+        BRX_HIP(hipMalloc((void **)&dv.d_out, dv.out_cap));
+        st = brx_chain_correct_batch_device(chain, dv.d_in, dv.d_off, n, b.total, dv.d_out, dv.out_cap, dv.d_out_off,
+                                            &out_total, s);
+    }
+    BRX_TRY(st);
+    BRX_TRY(b.out.reserve(out_total + 64, 0));
+    if (out_total)
+        BRX_HIP(hipMemcpyAsync(b.out.p, dv.d_out, out_total, hipMemcpyDeviceToHost, s));
+    BRX_HIP(hipMemcpyAsync(b.out_offsets.data(), dv.d_out_off, ((size_t)n + 1) * 8, hipMemcpyDeviceToHost, s));
+    BRX_HIP(hipStreamSynchronize(s));
+    return BRX_OK;
+}
+
+void format_batch(const Batch &b, std::vector<char> &o)
+{
+    const uint32_t n = b.n();
+    const uint64_t out_total = n ? b.out_offsets[n] : 0;
+    // exact size first, then raw copies (a vector insert per 80-byte line costs more than the copy itself)
+    uint64_t need = b.defs.size() + 2ull * n + out_total;
+    for (uint32_t r = 0; r < n; r++) {
+        const uint64_t len = b.out_offsets[r + 1] - b.out_offsets[r];
+        need += (len + LINE_BASES - 1) / LINE_BASES;
+    }
+    o.resize(need);
+    char *w = o.data();
+    uint32_t dprev = 0;
+    for (uint32_t r = 0; r < n; r++) {
+        *w++ = '>';
+        const uint32_t dl = b.def_end[r] - dprev;
+        memcpy(w, b.defs.data() + dprev, dl);
+        w += dl;
+        dprev = b.def_end[r];
+        *w++ = '\n';
+        const char *seq = (const char *)b.out.p + b.out_offsets[r];
+        uint64_t len = b.out_offsets[r + 1] - b.out_offsets[r];
+        while (len >= LINE_BASES) {
+            memcpy(w, seq, LINE_BASES);
+            w += LINE_BASES;
+            *w++ = '\n';
+            seq += LINE_BASES;
+            len -= LINE_BASES;
+        }
+        if (len) {
+            memcpy(w, seq, len);
+            w += len;
+            *w++ = '\n';
+        }
+    }
+    o.resize((size_t)(w - o.data()));
+}
+
+} // namespace
+
+extern "C" {
+
+int brx_run_correction_fd(const brx_set_t *set, const brx_method_t *methods, uint32_t n_methods, bool two_side, int in_fd,
+                          int out_fd, uint32_t max_batch_records, uint64_t *stats8)
+{
+    if (!set || (!methods && n_methods) || n_methods == 0) {
+        set_error("null argument / empty method list");
+        return BRX_ERR_ARG;
+    }
+    BRX_TRY(use_device(set->device));
+    const int device = set->device;
+    const double t_start = now_s();
+    std::vector<Batch> slots(N_SLOTS);
+    Queue<Batch *> q_free, q_ready;
+    // the writer needs the batches in stream order: done batches wait in a small map keyed by sequence number
+    std::mutex done_mu;
+    std::condition_variable done_cv;
+    std::vector<Batch *> done; // unordered, few entries
+    bool gpu_finished = false;
+    Shared sh;
+    uint64_t n_records = 0, bases_in = 0, bases_out = 0, n_batches = 0;
+    double t_read = 0, t_gpu = 0, t_write = 0;
+    for (auto &s : slots)
+        q_free.push(&s);
+
+    std::thread reader([&] {
+        if (hipSetDevice(device) != hipSuccess) { // pinned allocations belong to this device's context
+            set_error("hipSetDevice in reader thread failed");
+            sh.fail(BRX_ERR_HIP);
+            q_ready.close();
+            return;
+        }
+        FastaBatcher fb(in_fd, max_batch_records);
+        uint64_t seq = 0;
+        for (;;) {
+            Batch *b = nullptr;
+            if (!q_free.pop(b) || sh.failed())
+                break;
+            const double t0 = now_s();
+            int st = fb.fill(*b);
+            t_read += now_s() - t0;
+            if (st != BRX_OK) {
+                sh.fail(st);
+                break;
+            }
+            b->seq = seq++;
+            const bool last = b->last;
+            q_ready.push(b);
+            if (last)
+                break;
+        }
+        q_ready.close();
+    });
+
+    auto gpu_worker = [&]() {
+        brx_chain_t *chain = nullptr;
+        hipStream_t s = nullptr;
+        DevBufs dv;
+        int st = use_device(device);
+        if (st == BRX_OK)
+            st = brx_chain_new(set, methods, n_methods, two_side, &chain);
+        if (st == BRX_OK && hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) {
+            set_error("hipStreamCreate failed");
+            st = BRX_ERR_HIP;
+        }
+        if (st != BRX_OK)
+            sh.fail(st);
+        Batch *b = nullptr;
+        while (q_ready.pop(b)) {
+            if (!sh.failed()) {
+                const double t0 = now_s();
+                st = correct_one_batch(chain, dv, s, *b);
+                const double dt = now_s() - t0;
+                if (st != BRX_OK)
+                    sh.fail(st);
+                std::lock_guard<std::mutex> g(done_mu);
+                t_gpu += dt;
+            }
+            {
+                std::lock_guard<std::mutex> g(done_mu);
+                done.push_back(b);
+            }
+            done_cv.notify_all();
+        }
+        if (chain)
+            brx_chain_free(chain);
+        if (s)
+            (void)hipStreamDestroy(s);
+    };
+    std::thread gpu_a(gpu_worker), gpu_b(gpu_worker);
+
+    std::thread writer([&] {
+        std::vector<char> obuf;
+        uint64_t next = 0;
+        for (;;) {
+            Batch *b = nullptr;
+            {
+                std::unique_lock<std::mutex> g(done_mu);
+                done_cv.wait(g, [&] {
+                    for (auto *d : done)
+                        if (d->seq == next)
+                            return true;
+                    return gpu_finished;
+                });
+                for (size_t i = 0; i < done.size(); i++)
+                    if (done[i]->seq == next) {
+                        b = done[i];
+                        done.erase(done.begin() + (long)i);
+                        break;
+                    }
+                if (!b)
+                    return; // GPU side finished and nothing in order is left
+            }
+            next++;
+            if (!sh.failed()) {
+                const double t0 = now_s();
+                format_batch(*b, obuf);
+                int st = write_all(out_fd, obuf.data(), obuf.size());
+                t_write += now_s() - t0;
+                if (st != BRX_OK)
+                    sh.fail(st);
+                n_records += b->n();
+                bases_in += b->total;
+                bases_out += b->n() ? b->out_offsets[b->n()] : 0;
+                n_batches++;
+            }
+            q_free.push(b);
+        }
+    });
+
+    reader.join();
+    gpu_a.join();
+    gpu_b.join();
+    {
+        std::lock_guard<std::mutex> g(done_mu);
+        gpu_finished = true;
+    }
+    done_cv.notify_all();
+    writer.join();
+    q_free.close();
+    if (stats8) {
+        stats8[0] = n_records;
+        stats8[1] = bases_in;
+        stats8[2] = bases_out;
+        stats8[3] = n_batches;
+        stats8[4] = (uint64_t)(t_read * 1e9);
+        stats8[5] = (uint64_t)(t_gpu * 1e9);
+        stats8[6] = (uint64_t)(t_write * 1e9);
+        stats8[7] = (uint64_t)((now_s() - t_start) * 1e9);
+    }
+    if (sh.status != BRX_OK) {
+        set_error("%s", sh.message.c_str());
+        return sh.status;
+    }
+    return BRX_OK;
+}
+
+int brx_count_fasta_fd(brx_counter_t *c, int in_fd, uint32_t max_batch_records, uint64_t *stats8)
+{
+    if (!c) {
+        set_error("null counter");
+        return BRX_ERR_ARG;
+    }
+    BRX_TRY(use_device(c->device));
+    const int device = c->device;
+    const double t_start = now_s();
+    std::vector<Batch> slots(3);
+    Queue<Batch *> q_free, q_ready;
+    Shared sh;
+    double t_read = 0, t_gpu = 0;
+    uint64_t n_records = 0, bases_in = 0, n_batches = 0;
+    for (auto &s : slots)
+        q_free.push(&s);
+    std::thread reader([&] {
+        if (hipSetDevice(device) != hipSuccess) {
+            set_error("hipSetDevice in reader thread failed");
+            sh.fail(BRX_ERR_HIP);
+            q_ready.close();
+            return;
+        }
+        FastaBatcher fb(in_fd, max_batch_records);
+        for (;;) {
+            Batch *b = nullptr;
+            if (!q_free.pop(b) || sh.failed())
+                break;
+            const double t0 = now_s();
+            int st = fb.fill(*b);
+            t_read += now_s() - t0;
+            if (st != BRX_OK) {
+                sh.fail(st);
+                break;
+            }
+            const bool last = b->last;
+            q_ready.push(b);
+            if (last)
+                break;
+        }
+        q_ready.close();
+    });
+    DevBufs dv;
+    hipStream_t s = c->stream;
+    Batch *b = nullptr;
+    while (q_ready.pop(b)) {
+        if (!sh.failed() && b->n()) {
+            const double t0 = now_s();
+            int st = dv.ensure(b->total, b->n());
+            hipError_t e = hipSuccess;
+            if (st == BRX_OK && b->total)
+                e = hipMemcpyAsync(dv.d_in, b->bases.p, b->total, hipMemcpyHostToDevice, s);
+            if (st == BRX_OK && e == hipSuccess)
+                e = hipMemcpyAsync(dv.d_off, b->offsets.data(), ((size_t)b->n() + 1) * 8, hipMemcpyHostToDevice, s);
+            if (st == BRX_OK && e == hipSuccess)
+                st = brx_set_count_add_batch_device(c, dv.d_in, dv.d_off, b->n(), b->total, s);
+            if (st == BRX_OK && e == hipSuccess)
+                e = hipStreamSynchronize(s); // the batch's device buffers are reused by the next one
+            if (e != hipSuccess) {
+                set_error("count_fasta: %s", hipGetErrorString(e));
+                st = BRX_ERR_HIP;
+            }
+            t_gpu += now_s() - t0;
+            if (st != BRX_OK)
+                sh.fail(st);
+            n_records += b->n();
+            bases_in += b->total;
+            n_batches++;
+        }
+        q_free.push(b);
+    }
+    reader.join();
+    q_free.close();
+    if (stats8) {
+        for (int i = 0; i < 8; i++)
+            stats8[i] = 0;
+        stats8[0] = n_records;
+        stats8[1] = bases_in;
+        stats8[3] = n_batches;
+        stats8[4] = (uint64_t)(t_read * 1e9);
+        stats8[5] = (uint64_t)(t_gpu * 1e9);
+        stats8[7] = (uint64_t)((now_s() - t_start) * 1e9);
+    }
+    if (sh.status != BRX_OK) {
+        set_error("%s", sh.message.c_str());
+        return sh.status;
+    }
+    return BRX_OK;
+}
+
+} // extern "C"

@@ -223,6 +223,16 @@ class Counter:
         _lib.check(_lib.lib().brx_set_count_add_batch(self._h, bases.ctypes.data, offsets.ctypes.data,
                                                       offsets.size - 1))
 
+    def count_fasta(self, f) -> dict:
+        """Counter::count_fasta(reader, record_buffer) (src/main.rs:73-78) through the native host pipeline
+        (brx_count_fasta_fd): every record of the FASTA stream `f` (a binary file object)."""
+        from . import hostio
+        st = (C.c_uint64 * 8)()
+        with hostio.input_fd(f) as fd:
+            _lib.check(_lib.lib().brx_count_fasta_fd(self._h, fd, 0, st))
+        return {"records": int(st[0]), "bases_in": int(st[1]), "batches": int(st[3]), "ns_parse": int(st[4]),
+                "ns_gpu": int(st[5]), "ns_wall": int(st[7])}
+
     def add_batch_device(self, d_bases: int, d_offsets: int, n_reads: int, total_bases: int,
                          stream: Optional[int] = None) -> None:
         _lib.check(_lib.lib().brx_set_count_add_batch_device(self._h, d_bases, d_offsets, n_reads, total_bases,

@@ -186,6 +186,20 @@ int brx_chain_last_stats(const brx_chain_t *chain, uint64_t *stats8);
 void brx_chain_free(brx_chain_t *chain);
 void brx_buf_free(void *p);
 
+/* ---- host pipelines over file descriptors ----------------------------------------
+ * run_correction (src/lib.rs:22-139) for ONE input/output pair: FASTA records are parsed from in_fd (plain
+ * text; decompress upstream), corrected by build_methods(methods) against `set` (reverse pass unless
+ * two_side), and written to out_fd in input order as '>name[ description]' + the sequence wrapped at 80
+ * columns (noodles' reader / writer conventions, restated; unpinned by the reference's tests).  Parsing, the
+ * GPU (two chains on two streams) and formatting run on their own threads.  A malformed record ends the
+ * stream silently after the records before it (src/lib.rs:35).  max_batch_records 0 = default; the batch
+ * size does not change a byte of the output.
+ * stats8: [0] records, [1] bases in, [2] bases out, [3] batches, [4..7] ns parsing / GPU / writing / wall.  */
+int brx_run_correction_fd(const brx_set_t *set, const brx_method_t *methods, uint32_t n_methods, bool two_side, int in_fd,
+                          int out_fd, uint32_t max_batch_records, uint64_t *stats8);
+/* Counter::count_fasta(reader, record_buffer) (src/main.rs:73-78): counts every record of the FASTA stream */
+int brx_count_fasta_fd(brx_counter_t *c, int in_fd, uint32_t max_batch_records, uint64_t *stats8);
+
 /* ---- synthetic reads: deterministic, identical on host and device ----------
  * genome: i.i.d. uniform ACGT of length genome_len (seed); read r: window of read_len
  * reference bases at a uniform start, strand +/- with p=1/2, per-reference-base errors

@@ -1,0 +1,121 @@
+"""The native host pipeline (brx_run_correction_fd / brx_count_fasta_fd: FASTA parse -> GPU -> FASTA write on
+threads) against the record-by-record Python driver and the oracle: same bytes, whatever the batch size,
+the line structure of the input or the kind of file object."""
+import gzip
+import io
+import os
+
+import numpy as np
+import pytest
+
+import br_amd
+from br_amd import fasta
+from br_amd.driver import run_correction
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _expected(text: bytes, om, two_side: bool) -> bytes:
+    out = io.BytesIO()
+    for name, desc, seq in fasta.read_records(io.BytesIO(text)):
+        fasta.write_record(out, name, desc, O.correct_record(om, seq, two_side))
+    return out.getvalue()
+
+
+@pytest.mark.parametrize("batch_records", [0, 7, 64])
+@pytest.mark.parametrize("two_side", [False, True])
+def test_native_pipeline_fixture(tmp_path, golden_dir, solid_fixture_bytes, batch_records, two_side):
+    gs = br_amd.Pcon.from_pcon_solid(solid_fixture_bytes)
+    os_ = O.Solid.from_bytes(solid_fixture_bytes)
+    om = O.build_methods(os_, ["one", "graph"], 5, 7)
+    methods = br_amd.build_methods(["one", "graph"], gs, 5, 7)
+    src = os.path.join(golden_dir, "raw.fasta")
+    dst = tmp_path / "corr.fasta"
+    with open(src, "rb") as fi, open(dst, "wb") as fo:
+        st = run_correction([fi], [fo], methods, two_side, native=True, batch_records=batch_records)
+    want = _expected(open(src, "rb").read(), om, two_side)
+    assert dst.read_bytes() == want
+    assert st["records"] == 206 and st["bases_in"] == 2519592
+    if batch_records == 7:
+        assert st["batches"] >= 206 // 7
+    # the Python driver says the same
+    out = io.BytesIO()
+    with open(src, "rb") as fi:
+        run_correction([fi], [out], methods, two_side, native=False)
+    assert out.getvalue() == want
+
+
+EDGE = (b">r1 first read \t with   description  \r\n"
+        b"ACGTACGTTTGACCAGTACGATCGATCGGGATCAGCTAGCATCGACTAGCTAGCATCGATCAGCATCGACTAGCATCGACTAGCTACGACTAGCATCAGCATCAGCT\r\n"
+        b"acgtnnACGTTGCA\n"
+        b"\n"
+        b"GGGTTTAAACCC\r\r\n"
+        b">r2\n"
+        b">r3\tdesc\n"
+        b"ACGT\n"
+        b">r4 last one without newline at the end\n"
+        b"TTGACCAGTACGATCGATCGGGATCAGCTAGCATCGACTAGCTAGCATCGATCAGCATCGACTAGCATCGACTAGCTACGACTAGCATCAGCATCAGCTAAAAAAAAAAAAAAAAAAAAAAAAAAAACCCCCCCCCCCGGGGGGGT")
+
+
+@pytest.mark.parametrize("tail", [b"", b"\n>\nACGT\n>r6\nACGT\n", b"\n> leading space\nACGT\n"])
+def test_native_pipeline_edge_cases(solid_fixture_bytes, tail):
+    """CRLF, blank and wrapped sequence lines, descriptions, an empty record, a missing final newline; a
+    definition without a name ends the stream silently after the records before it (src/lib.rs:35)."""
+    gs = br_amd.Pcon.from_pcon_solid(solid_fixture_bytes)
+    os_ = O.Solid.from_bytes(solid_fixture_bytes)
+    om = O.build_methods(os_, ["one"], 5, 7)
+    methods = br_amd.build_methods(["one"], gs, 5, 7)
+    text = EDGE + tail
+    want = _expected(text, om, False)
+    assert want.count(b">") == 4
+    for batch_records in (0, 1, 3):
+        out = io.BytesIO()  # BytesIO on both sides: pipe bridges
+        st = run_correction([io.BytesIO(text)], [out], methods, False, native=True, batch_records=batch_records)
+        assert out.getvalue() == want
+        assert st["records"] == 4
+
+
+def test_native_pipeline_rejects_data_before_definition(solid_fixture_bytes):
+    gs = br_amd.Pcon.from_pcon_solid(solid_fixture_bytes)
+    methods = br_amd.build_methods(["one"], gs, 5, 7)
+    out = io.BytesIO()
+    st = run_correction([io.BytesIO(b"ACGT\n>r1\nACGT\n")], [out], methods, False, native=True)
+    assert out.getvalue() == b"" and st["records"] == 0
+    out = io.BytesIO()
+    run_correction([io.BytesIO(b"")], [out], methods, False, native=True)
+    assert out.getvalue() == b""
+
+
+def test_native_pipeline_gzip_input_and_many_batches(tmp_path, golden_dir, solid_fixture_bytes):
+    gs = br_amd.Pcon.from_pcon_solid(solid_fixture_bytes)
+    os_ = O.Solid.from_bytes(solid_fixture_bytes)
+    om = O.build_methods(os_, ["one"], 5, 7)
+    methods = br_amd.build_methods(["one"], gs, 5, 7)
+    raw = open(os.path.join(golden_dir, "raw.fasta"), "rb").read()
+    gz = tmp_path / "raw.fasta.gz"
+    with gzip.open(gz, "wb") as f:
+        f.write(raw)
+    dst = tmp_path / "corr.fasta"
+    with gzip.open(gz, "rb") as fi, open(dst, "wb") as fo:
+        st = run_correction([fi], [fo], methods, False, native=True, batch_records=5)
+    assert dst.read_bytes() == _expected(raw, om, False)
+    assert st["batches"] >= 41
+
+
+@pytest.mark.parametrize("strategy", ["auto", "dense"])
+def test_count_fasta_native(golden_dir, solid_fixture_bytes, strategy):
+    """`br fasta -k 11 -a 2` through brx_count_fasta_fd rebuilds the reference's own .solid fixture."""
+    from br_amd import _lib
+    cnt = br_amd.Counter(11, 0, {"auto": _lib.COUNT_AUTO, "dense": _lib.COUNT_DENSE}[strategy])
+    with open(os.path.join(golden_dir, "raw.fasta"), "rb") as f:
+        st = cnt.count_fasta(f)
+    assert st["records"] == 206 and st["bases_in"] == 2519592
+    assert cnt.finish(2).to_solid_bytes() == solid_fixture_bytes
+    # k = 15 goes the partitioned way; compare with the oracle's count
+    cnt = br_amd.Counter(15, 0)
+    with open(os.path.join(golden_dir, "raw.fasta"), "rb") as f:
+        cnt.count_fasta(f)
+    reads = [seq for _, _, seq in fasta.read_records(open(os.path.join(golden_dir, "raw.fasta"), "rb"))][:]
+    ref = O.Solid.from_count(15, O.count_reads(15, reads), 1)
+    assert cnt.finish(1).to_solid_bytes() == ref.to_bytes()
