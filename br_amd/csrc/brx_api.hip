@@ -2,6 +2,8 @@
 #include "brx_internal.hpp"
 
 #include <stdio.h>
+#include <stdlib.h>
+#include <chrono>
 #include <string.h>
 #include <map>
 
@@ -33,6 +35,18 @@ int use_device(int device)
     }
     BRX_HIP(hipSetDevice(device));
     return BRX_OK;
+}
+
+void trace_stage(hipStream_t s, const char *what)
+{
+    static const bool on = [] { const char *e = getenv("BRX_TRACE"); return e && *e && *e != '0'; }();
+    if (!on)
+        return;
+    static const auto t0 = std::chrono::steady_clock::now();
+    const hipError_t e = hipStreamSynchronize(s);
+    fprintf(stderr, "[brx %9.3f s] %s%s%s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(), what,
+            e == hipSuccess ? "" : " -> ", e == hipSuccess ? "" : hipGetErrorString(e));
+    fflush(stderr);
 }
 
 // ---- timers ---------------------------------------------------------------------------------

@@ -33,6 +33,9 @@ void set_error(const char *fmt, ...);
 // BRX_OK if `device` is a usable GPU and has been made current
 int use_device(int device);
 
+// BRX_TRACE=1: synchronise `s` and print a time-stamped stage name on stderr (finding where a big job stalls)
+void trace_stage(hipStream_t s, const char *what);
+
 // ---- per-kernel HIP-event timers -----------------------------------------------------------
 // Usage: { KernelTimer t("correct_pass", stream); launch<<<...,stream>>>(); }
 // Events are recorded on the launch stream and resolved lazily by brx_profile_get.

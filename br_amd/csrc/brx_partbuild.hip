@@ -525,9 +525,12 @@ __global__ __launch_bounds__(64 * P3_WAVES) void final_count_kernel(const uint16
         const uint32_t off_lo = (uint32_t)offv, off_hi = (uint32_t)(offv >> 32);
         for (int j = 0; j < gcount; j++) {
             // j is wave-uniform: v_readlane instead of a bpermute through the LDS pipe
-            const uint64_t s = ((uint64_t)__builtin_amdgcn_readlane(off_hi, j) << 32) | __builtin_amdgcn_readlane(off_lo, j);
-            const uint64_t e = ((uint64_t)__builtin_amdgcn_readlane(off_hi, j + 1) << 32) |
-                               __builtin_amdgcn_readlane(off_lo, j + 1);
+            // (the builtin returns a signed int: without the casts an offset with bit 31 set sign-extends over the
+            // high word -- every job beyond 2^31 keys)
+            const uint64_t s = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(off_hi, j) << 32) |
+                               (uint64_t)(uint32_t)__builtin_amdgcn_readlane(off_lo, j);
+            const uint64_t e = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(off_hi, j + 1) << 32) |
+                               (uint64_t)(uint32_t)__builtin_amdgcn_readlane(off_lo, j + 1);
             const uint64_t n = e - s;
             bool any_bit = false;
             if (n == 0) {
@@ -865,12 +868,14 @@ int part_add_batch(brx_counter *c, const uint8_t *d_bases, const uint64_t *d_off
         KernelTimer t("part_l1_hist", s);
         l1_hist_kernel<<<grid, 256, (size_t)B * 4, s>>>(a);
     }
+    trace_stage(s, "partition level 1: histograms");
     BRX_TRY(exclusive_scan_lens(st->d_matrix, (uint32_t)n_entries, st->d_scan_tmp, st->d_pos, st->d_scalars + 1, s));
     l1_coff_kernel<<<(B + 1 + 255) / 256, 256, 0, s>>>(st->d_pos, B, n_items, b.d_l1off);
     {
         KernelTimer t("part_l1_scatter", s);
         l1_scatter_kernel<<<grid, 256, scatter_lds_bytes(L1_TILE, a.bits), s>>>(a);
     }
+    trace_stage(s, "partition level 1: scatter");
     BRX_HIP(hipGetLastError());
     unsigned long long tot = 0;
     BRX_HIP(hipMemcpyAsync(&tot, st->d_scalars + 1, 8, hipMemcpyDeviceToHost, s));
@@ -910,6 +915,7 @@ static int run_level(PartState *st, int l, const uint32_t *keys_in, const uint64
     tiles_from_offsets_kernel<<<(unsigned)((n_parents + 255) / 256), 256, 0, s>>>(poff, n_parents, tile, st->d_ntiles);
     BRX_TRY(exclusive_scan_lens(st->d_ntiles, (uint32_t)n_parents, st->d_scan_tmp, st->d_item_off, st->d_scalars, s));
     fill_item_parent_kernel<<<(unsigned)((n_parents + 255) / 256), 256, 0, s>>>(st->d_item_off, n_parents, st->d_item_parent);
+    trace_stage(s, tag_hist);
     BRX_HIP(hipMemsetAsync(st->d_matrix, 0, n_entries * 4, s));
     LnArgs a;
     memset(&a, 0, sizeof(a));
@@ -933,6 +939,7 @@ static int run_level(PartState *st, int l, const uint32_t *keys_in, const uint64
         else
             ln_hist_kernel<16><<<grid, 256, (size_t)B * 4, s>>>(a);
     }
+    trace_stage(s, "  histograms done");
     BRX_TRY(exclusive_scan_lens(st->d_matrix, (uint32_t)n_entries, st->d_scan_tmp, st->d_pos, st->d_scalars + 1, s));
     {
         const uint64_t nc = n_parents * B + 1;
@@ -946,6 +953,7 @@ static int run_level(PartState *st, int l, const uint32_t *keys_in, const uint64
         else
             ln_scatter_kernel<16, OUT><<<grid, 256, lds, s>>>(a);
     }
+    trace_stage(s, tag_scatter);
     BRX_HIP(hipGetLastError());
     return BRX_OK;
 }
@@ -1038,6 +1046,7 @@ int part_finish_into(brx_counter *c, uint32_t abundance, hipStream_t s, brx_set 
                                                                     nullptr, 0, nullptr);
     }
     BRX_HIP(hipGetLastError());
+    trace_stage(s, "final count");
     dst->keylist_valid = emit;
     return BRX_OK;
 }

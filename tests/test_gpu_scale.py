@@ -148,3 +148,36 @@ def test_sample_of_reads_matches_oracle(job):
             assert got == O.correct_record(om, src, False), (methods, r)
         st = chain.last_stats()
         assert st["fixes"] > 10_000_000
+
+
+def test_more_than_2_31_kmers_in_one_counter():
+    """2.3 Gbp in one batch: key offsets beyond 2^31 (a sign-extended lane read once sent the final counting
+    pass into an endless loop there).  Property check instead of the oracle: at 50x coverage nearly every
+    k-mer of the genome is solid, a random 19-mer is not."""
+    import torch
+    n_reads = 230_000
+    cfg = synth.config(genome_len=n_reads * READ_LEN // 50, read_len=READ_LEN)
+    stream = torch.cuda.current_stream().cuda_stream
+    dg = torch.empty(cfg.genome_len, dtype=torch.uint8, device="cuda")
+    synth.genome_device(cfg, 0, dg.data_ptr(), stream)
+    cap = int(n_reads * READ_LEN * 1.03) + (1 << 20)
+    db = torch.empty(cap, dtype=torch.uint8, device="cuda")
+    do = torch.empty(n_reads + 1, dtype=torch.int64, device="cuda")
+    total = synth.reads_device(cfg, 0, dg.data_ptr(), 0, n_reads, db.data_ptr(), cap, do.data_ptr(), stream)
+    assert total > (1 << 31)
+    cnt = br_amd.Counter(K, 0, _lib.COUNT_SORTED)
+    cnt.add_batch_device(db.data_ptr(), do.data_ptr(), n_reads, total, stream)
+    solid = cnt.finish(ABUNDANCE, stream)
+    del cnt, db
+    n_solid = solid.popcount()
+    assert 0.95 * cfg.genome_len < n_solid < 1.2 * cfg.genome_len
+    g = dg[:200_000].cpu().numpy()
+    code = (g >> 1) & 3
+    kmers = np.zeros(len(g) - K + 1, dtype=np.uint64)
+    for j in range(K):
+        kmers = (kmers << np.uint64(2)) | code[j:j + len(kmers)].astype(np.uint64)
+    assert solid.get_many(kmers).mean() > 0.98  # (the first 10 kb of the genome are covered thinly)
+    rnd = np.random.default_rng(3).integers(0, 1 << (2 * K), size=100_000, dtype=np.uint64)
+    assert solid.get_many(rnd).mean() < 0.01
+    kl = solid.keylist_device(stream)
+    assert kl is not None and kl[1] == n_solid
