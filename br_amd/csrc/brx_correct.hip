@@ -974,15 +974,11 @@ __global__ __launch_bounds__(256, (M == BRX_ONE ? 6 : 1)) void correct_kernel(Pa
                     }
                     npath++;
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                    int off = 0;
-                    const bool found = greedy_align<G>(gL, gl, k - 1 + (int)git, k - 1 + (int)gnl, k - 1, off);
-                    if (found) {
-                        goff = off;
-                        sub = 0;
-                        st = ST_GVALID;
-                    } else if (++git >= (uint32_t)p.max_search) {
-                        fail = true;
-                    }
+                    // greedy.rs:163-168 returns Some iff match_alignement finds an offset AND check_next_kmers
+                    // holds.  Both are pure, so the cheap one goes first: the c look-ahead probes (GVALID), and the
+                    // (k+i)^2 alignment only for the few candidates that pass them.
+                    sub = 0;
+                    st = ST_GVALID;
                 }
             } else if (HAS_GREEDY && st == ST_GVALID) {
                 const uint32_t rem2 = n - i - git;
@@ -999,6 +995,10 @@ __global__ __launch_bounds__(256, (M == BRX_ONE ? 6 : 1)) void correct_kernel(Pa
                 }
                 if (!ok) {
                     st = ST_GFOLLOW;
+                    if (++git >= (uint32_t)p.max_search)
+                        fail = true;
+                } else if (done && !greedy_align<G>(gL, gl, k - 1 + (int)git, k - 1 + (int)gnl, k - 1, goff)) {
+                    st = ST_GFOLLOW; // the look-ahead held but no alignment offset: next iteration (greedy.rs:163)
                     if (++git >= (uint32_t)p.max_search)
                         fail = true;
                 } else if (done) {
