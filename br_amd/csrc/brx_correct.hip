@@ -315,10 +315,13 @@ __device__ bool greedy_align(const GreedyLds &L, int gl, int m, int n, int nb, i
 }
 
 // look-ahead k-mers per scenario probed in the SCEN round that starts at look-ahead index `sub`
-__device__ __forceinline__ uint32_t scen_width(uint32_t sub, uint32_t c, int G, uint32_t flags)
+// (the lanes are dealt to the scenarios still alive, so once the wrong ones have died the survivor's
+// remaining look-aheads fit one round even in an 8-lane group)
+__device__ __forceinline__ uint32_t scen_width(uint32_t sub, uint32_t c, int G, uint32_t flags, uint32_t failmask)
 {
     const uint32_t left = c - sub;
-    const uint32_t cap = (sub == 0u && !(flags & 4u)) ? 2u : (uint32_t)G / 3u;
+    const uint32_t alive = 3u - (uint32_t)__popc(failmask & 7u);
+    const uint32_t cap = (sub == 0u && !(flags & 4u)) ? 2u : (uint32_t)G / (alive ? alive : 1u);
     return left < cap ? left : cap;
 }
 
@@ -531,13 +534,15 @@ __global__ __launch_bounds__(256, (M == BRX_ONE ? 6 : 1)) void correct_kernel(Pa
                 // get_score look-ahead, staged: look-ahead k-mers [sub, sub+width) of the three
                 // scenarios per round (first the two nearest ones: a wrong scenario almost always dies
                 // there, so its remaining probes are never issued).  Same verdict as probing all c.
-                const uint32_t width = scen_width(sub, c, G, p.flags);
+                const uint32_t width = scen_width(sub, c, G, p.flags, failmask);
                 const uint32_t e = (uint32_t)gl;
-                sc_active = e < 3u * width;
-                sc_s = sc_active ? e / width : 0u;
+                const uint32_t alive = ~failmask & 7u; // never 0 here
+                const uint32_t ord = e / width;        // which surviving scenario this lane works for
+                sc_active = ord < (uint32_t)__popc(alive);
+                const uint32_t a1 = alive & (alive - 1u);
+                sc_s = !sc_active ? 0u : (ord == 0u ? (uint32_t)__ffs(alive) - 1u : (ord == 1u ? (uint32_t)__ffs(a1) - 1u : 2u));
                 const uint32_t j = sub + (sc_active ? e % width : 0u);
                 const uint32_t off = 2u - sc_s; // I:2 S:1 D:0 (one.rs:57-63)
-                sc_active = sc_active && !((failmask >> sc_s) & 1u);
                 if (sc_active) {
                     if (c + 3u <= (uint32_t)WB && !(p.flags & 8u)) {
                         pk = ext(corr, win, off, j + 1u);
@@ -823,13 +828,14 @@ __global__ __launch_bounds__(256, (M == BRX_ONE ? 6 : 1)) void correct_kernel(Pa
                 }
             } else if (HAS_ONE && st == ST_SCEN) {
                 const bool bad = sc_active && !sol;
+                const uint32_t w_used = scen_width(sub, c, G, p.flags, failmask); // as dealt in phase 1
 #pragma unroll
                 for (uint32_t s = 0; s < 3; s++) {
                     const uint64_t b = (__ballot(bad && sc_s == s) >> gshift) & GM;
                     if (b)
                         failmask |= 1u << s;
                 }
-                sub += scen_width(sub, c, G, p.flags);
+                sub += w_used;
                 if (failmask == 7u) {
                     fail = true; // exist/mod.rs:132-134
                 } else if (sub >= c) {
