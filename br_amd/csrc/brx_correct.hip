@@ -360,6 +360,7 @@ __global__ __launch_bounds__(256, (M == BRX_ONE ? 6 : 1)) void correct_kernel(Pa
     int st = ST_INIT, mode = HAS_TWO ? MODE_TWO : (M == BRX_GRAPH ? MODE_GRAPH : MODE_ONE);
     uint32_t sub = 0, failmask = 0, passmask = 0;
     uint8_t ch_t = 0;
+    uint32_t hop = 0;  // consecutive re-runs of the current round (sparse sets: which line of the chain is probed)
     bool slow = false; // this round is the bitset re-run of a round the probe index could not answer
     bool was_unres = false, kept_sol = false; // per lane: its probe of that round was unanswered / its answer
     // error_len / walk state
@@ -647,13 +648,20 @@ __global__ __launch_bounds__(256, (M == BRX_ONE ? 6 : 1)) void correct_kernel(Pa
                     unres = pr == 2;
                     n_probes++;
                 } else if (was_unres) {
-                    sol = probe(p.bits, pk, k);
+                    if (p.bits) {
+                        sol = probe(p.bits, pk, k);
+                    } else { // sparse set: the build chained the key into the hop-th line after its own
+                        const int pr = index_probe(p.idx, pk, k, hop);
+                        sol = pr == 1;
+                        unres = pr == 2;
+                    }
                     n_probes++;
                 } else {
                     sol = kept_sol; // answered by the index in the round being repeated
                 }
             }
             retry = ((__ballot(unres) >> gshift) & GM) != 0ull;
+            hop = retry ? hop + 1u : 0u;
             slow = retry;
             was_unres = unres;
             kept_sol = sol;
@@ -1389,7 +1397,7 @@ int brx_chain_correct_batch_device(brx_chain_t *ch, const uint8_t *d_bases, cons
     // probe index of the set (built here when the set has none yet, e.g. after a finish_into)
     BRX_TRY(index_ensure(ch->set, s));
     IdxView idx{nullptr, 0, 0, 0};
-    if (ch->set->idx_valid && index_wanted(k))
+    if (ch->set->idx_valid && (index_wanted(k) || ch->set->sparse))
         idx = IdxView{ch->set->d_lines, 32u - ch->set->idx_log_lines, ch->set->idx_m, (uint32_t)k - ch->set->idx_m + 1u};
 
     const int n_dirs = ch->two_side ? 1 : 2;
@@ -1438,7 +1446,7 @@ int brx_chain_correct_batch_device(brx_chain_t *ch, const uint8_t *d_bases, cons
                 // trigger-free) reverse scans.  Walks probe 4 successors of one k-mer per round: measured
                 // 10-15 % slower through the index (Graph, GapSize forward), Greedy 78 % slower.
                 const int mth = ch->methods[m].method;
-                const bool use_idx = mth == BRX_ONE || (dir == 1 && mth != BRX_GREEDY);
+                const bool use_idx = ch->set->sparse || mth == BRX_ONE || (dir == 1 && mth != BRX_GREEDY);
                 p.idx = use_idx ? idx : IdxView{nullptr, 0, 0, 0};
                 p.k = k;
                 p.c = ch->methods[m].confirm;

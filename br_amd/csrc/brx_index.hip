@@ -8,29 +8,41 @@ using namespace brx;
 
 namespace {
 
-// one key per thread: claim a slot of the key's line, or flag the line as overflowed
+// one key per thread: claim a slot of the key's line; a full line is flagged as overflowed and the key is
+// left to the bit vector (CHAIN = false) or goes on to the next line (CHAIN = true: sparse sets)
+template <bool CHAIN>
 __global__ __launch_bounds__(256) void index_insert_kernel(const uint64_t *__restrict__ keys, uint64_t n, uint64_t *__restrict__ lines,
                                                            uint32_t line_shift, uint32_t m, uint32_t w, int k,
                                                            unsigned long long *__restrict__ n_overflow)
 {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    const uint32_t line_mask = 0xffffffffu >> line_shift;
     uint32_t lost = 0;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         const uint64_t h = keys[i];
         const uint64_t canon = (h << 1) | (uint64_t)(popc64(h) & 1); // even popcount (brx_kmer.hpp)
         const uint64_t rc = revcomp(canon, k);
-        const uint32_t line = index_line_of(minimizer_of(canon, rc, m, w), line_shift);
-        unsigned long long *L = reinterpret_cast<unsigned long long *>(lines) + (uint64_t)line * 8ull;
-        const unsigned long long seen = __hip_atomic_load(L + 7, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        uint32_t slot = IDX_SLOTS;
-        if ((uint32_t)seen < (uint32_t)IDX_SLOTS) // full lines are not counted further: the counter stays small
-            slot = (uint32_t)atomicAdd(L + 7, 1ull);
-        if (slot < (uint32_t)IDX_SLOTS) {
-            L[slot] = h + 1ull;
-        } else {
+        uint32_t line = index_line_of(minimizer_of(canon, rc, m, w), line_shift);
+        bool counted = false;
+        for (;;) {
+            unsigned long long *L = reinterpret_cast<unsigned long long *>(lines) + (uint64_t)line * 8ull;
+            const unsigned long long seen = __hip_atomic_load(L + 7, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            uint32_t slot = IDX_SLOTS;
+            if ((uint32_t)seen < (uint32_t)IDX_SLOTS) // full lines are not counted further: the counter stays small
+                slot = (uint32_t)atomicAdd(L + 7, 1ull);
+            if (slot < (uint32_t)IDX_SLOTS) {
+                L[slot] = h + 1ull;
+                break;
+            }
             if (!(seen & IDX_OVERFLOW))
                 atomicOr(L + 7, (unsigned long long)IDX_OVERFLOW);
-            lost++;
+            if (!counted) {
+                lost++;
+                counted = true;
+            }
+            if (!CHAIN)
+                break;
+            line = (line + 1u) & line_mask; // the table has more slots than keys: this ends
         }
     }
     for (int d = 32; d > 0; d >>= 1)
@@ -48,9 +60,14 @@ __global__ void index_get_kernel(IdxView v, const uint32_t *__restrict__ bits, c
     const uint64_t fwd = kmers[i] & kmask(k);
     int r = index_probe(v, fwd, k);
     if (r == 2) {
-        const uint64_t h = khash(fwd, k);
-        r = (bits[h >> 5] >> (h & 31u)) & 1u;
         atomicAdd(n_fallback, 1ull);
+        if (bits) {
+            const uint64_t h = khash(fwd, k);
+            r = (bits[h >> 5] >> (h & 31u)) & 1u;
+        } else {
+            for (uint32_t hop = 1; r == 2; hop++) // sparse set: the key was chained into a following line
+                r = index_probe(v, fwd, k, hop);
+        }
     }
     out[i] = (uint8_t)r;
 }
@@ -67,6 +84,9 @@ namespace brx {
 
 bool index_wanted(int k)
 {
+    if (sparse_k(k))
+        return true; // nothing else to probe
+
     // below k = 15 the whole bitset (<= 4 MiB at k = 13) lives in every XCD's L2 and a plain probe is cheaper
     // (BRX_INDEX_MIN_K lowers the threshold: the parity tests run every corrector through the index at small k)
     return (k & 1) && k >= env_int("BRX_INDEX_MIN_K", 15) && k >= 5 && env_int("BRX_INDEX", 1) != 0;
@@ -113,6 +133,8 @@ static int index_build_locked(brx_set *set, const uint64_t *d_keys, uint64_t n, 
         while (log_lines < 28 && (1ull << log_lines) < n + n / 2)
             log_lines++;
     }
+    while (set->sparse && log_lines < 30 && (7ull << log_lines) < n + n / 4)
+        log_lines++; // a chained table must have room for every key
     if (log_lines < 4 || log_lines > 30) {
         set_error("probe index: log2(lines)=%d out of range 4..30", log_lines);
         return BRX_ERR_ARG;
@@ -143,8 +165,12 @@ static int index_build_locked(brx_set *set, const uint64_t *d_keys, uint64_t n, 
         uint64_t blocks = (n + 255) / 256;
         if (blocks > 256 * 16)
             blocks = 256 * 16;
-        index_insert_kernel<<<(int)blocks, 256, 0, s>>>(d_keys, n, set->d_lines, 32u - (uint32_t)log_lines, (uint32_t)m,
-                                                        (uint32_t)(k - m + 1), k, d_ovf);
+        if (set->sparse)
+            index_insert_kernel<true><<<(int)blocks, 256, 0, s>>>(d_keys, n, set->d_lines, 32u - (uint32_t)log_lines, (uint32_t)m,
+                                                                  (uint32_t)(k - m + 1), k, d_ovf);
+        else
+            index_insert_kernel<false><<<(int)blocks, 256, 0, s>>>(d_keys, n, set->d_lines, 32u - (uint32_t)log_lines, (uint32_t)m,
+                                                                   (uint32_t)(k - m + 1), k, d_ovf);
         e = hipGetLastError();
     }
     unsigned long long ovf = 0;
@@ -161,6 +187,7 @@ static int index_build_locked(brx_set *set, const uint64_t *d_keys, uint64_t n, 
     set->idx_m = (uint32_t)m;
     set->idx_keys = n;
     set->idx_overflow_keys = ovf;
+    set->idx_exact = set->sparse;
     set->idx_valid = true;
     return BRX_OK;
 }
@@ -174,7 +201,7 @@ int index_build_from_keys(brx_set *set, const uint64_t *d_keys, uint64_t n, int 
 int index_ensure(const brx_set *cset, hipStream_t s)
 {
     brx_set *set = const_cast<brx_set *>(cset);
-    if (!index_wanted(set->k))
+    if (!index_wanted(set->k) && !set->sparse)
         return BRX_OK;
     // several chains may share the set (one per host thread): exactly one of them builds, the others wait
     // here and find the index valid -- a second build would wipe lines the first chain's kernels are reading
@@ -195,7 +222,12 @@ int index_ensure(const brx_set *cset, hipStream_t s)
         BRX_HIP(hipStreamSynchronize(s)); // the bits may still be in flight on `s`; popcount runs on the null stream
         BRX_TRY(brx_set_popcount(set, &n));
     }
-    if (set->k - index_auto_m(set->k, n) + 1 < 3 && env_int("BRX_INDEX_M", 0) <= 0) {
+    if (set->sparse && !listed) {
+        set_error("sparse set without a complete key list (%llu solid k-mers counted, room for %llu)", (unsigned long long)n,
+                  (unsigned long long)set->keylist_cap);
+        return BRX_ERR_NOMEM;
+    }
+    if (!set->sparse && set->k - index_auto_m(set->k, n) + 1 < 3 && env_int("BRX_INDEX_M", 0) <= 0) {
         // so many keys that a safe minimizer is (nearly) the k-mer itself: neighbours would not share lines
         set->idx_declined = true;
         return BRX_OK;

@@ -8,7 +8,8 @@
 // strand-symmetric MINIMIZER (smallest hashed canonical m-mer inside the k-mer): consecutive k-mers of a
 // read share their minimizer for (k-m+2)/2 positions on average and the lanes that probe them share the
 // line.  The index is exact: a line lists full keys; a line that could not take all its keys is flagged
-// and a probe it cannot answer is re-issued against the bitset, which stays the source of truth.
+// and a probe it cannot answer is re-issued against the bitset, which stays the source of truth -- or, for
+// sparse sets (k >= 21, no bit vector), against the next line, where the build chained the key to.
 //
 // Line layout (8 x u64): [0..6] key+1 of up to 7 k-mers (0 = empty; key = canonical >> 1),
 // [7] header: low 32 bits = number of insert attempts, bit 63 = overflowed.
@@ -78,12 +79,13 @@ __device__ __forceinline__ uint32_t index_line_of(uint32_t mh, uint32_t line_shi
     return (mh * 0x85EBCA6Bu) >> line_shift;
 }
 
-// 1 = present, 0 = absent, 2 = the line overflowed and does not hold the key: ask the bitset
-__device__ __forceinline__ int index_probe(const IdxView &v, uint64_t fwd, int k)
+// 1 = present, 0 = absent, 2 = the line overflowed and does not hold the key: ask the bit vector, or -- sparse sets,
+// whose keys chain into the following lines -- probe again with hop + 1
+__device__ __forceinline__ int index_probe(const IdxView &v, uint64_t fwd, int k, uint32_t hop = 0)
 {
     const uint64_t rc = revcomp(fwd, k);
     const uint64_t key = (((popc64(fwd) & 1) ? rc : fwd) >> 1) + 1ull;
-    const uint32_t line = index_line_of(minimizer_of(fwd, rc, v.m, v.w), v.line_shift);
+    const uint32_t line = (index_line_of(minimizer_of(fwd, rc, v.m, v.w), v.line_shift) + hop) & (0xffffffffu >> v.line_shift);
     const ulonglong2 *L = reinterpret_cast<const ulonglong2 *>(v.lines + (uint64_t)line * 8ull);
     const ulonglong2 q0 = L[0], q1 = L[1], q2 = L[2], q3 = L[3];
     // `|`, not `||`: with short-circuit evaluation the compiler loads slot 0 first and fetches the rest of

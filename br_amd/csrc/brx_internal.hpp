@@ -62,7 +62,11 @@ struct brx_set {
     int k;
     int device;
     uint64_t nwords;   // u32 words
-    uint32_t *d_bits;  // nwords, zero padded
+    uint32_t *d_bits;  // nwords, zero padded; nullptr for a sparse set
+    // sparse set (k >= 21: 2^(2k-1) bits do not fit): the solid hashes live in the key list and in the probe
+    // index only, whose overflowing lines then chain into the next line instead of falling back to the bits
+    bool sparse;
+    bool idx_exact;          // the index was built with chaining (answers without the bit vector)
     // probe index over the same set (brx_index.hpp): built on demand, invalidated by every mutation
     // of the bits that goes through the ABI
     uint64_t *d_lines;       // 8 u64 per line
@@ -84,6 +88,8 @@ namespace brx {
 struct IdxView;
 // (re)builds the index from a device list of keys (bit indices = canonical >> 1); m / log_lines 0 = auto
 int index_build_from_keys(brx_set *set, const uint64_t *d_keys, uint64_t n, int m, int log_lines, hipStream_t s);
+// sets of this k have no bit vector
+inline bool sparse_k(int k) { return k >= 21; }
 // builds the index from the bitset when the set has none (no-op for k outside the indexed range)
 int index_ensure(const brx_set *set, hipStream_t s);
 inline void index_invalidate(brx_set *set) { set->idx_valid = false; set->idx_declined = false; set->keylist_valid = false; }

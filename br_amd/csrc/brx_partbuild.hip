@@ -41,7 +41,7 @@ using namespace brx;
 namespace {
 
 constexpr int F_BITS = 12;      // hashes per fine bucket = 4096 (8 KiB of u16 counters per wave)
-constexpr int MAX_LEVELS = 3;
+constexpr int MAX_LEVELS = 4;
 constexpr int MAX_DIGIT_BITS = 9;
 
 struct Plan {
@@ -58,11 +58,15 @@ Plan make_plan(int k)
     p.k = k;
     p.nbits = 2 * k - 1;
     const int P = p.nbits - F_BITS; // bits to partition away
-    p.nlev = P > 2 * MAX_DIGIT_BITS ? 3 : 2;
+    p.nlev = (P + MAX_DIGIT_BITS - 1) / MAX_DIGIT_BITS;
+    if (p.nlev < 2)
+        p.nlev = 2;
     int left = P, rem = p.nbits;
     uint64_t nb = 1;
     for (int l = 0; l < p.nlev; l++) {
-        const int b = (left + (p.nlev - l) - 1) / (p.nlev - l); // spread evenly, larger digits first
+        int b = (left + (p.nlev - l) - 1) / (p.nlev - l); // spread evenly, larger digits first
+        if (l == 0 && p.nbits - b > 32)
+            b = p.nbits - 32;                              // what is left after level 1 travels as u32 keys
         p.bits[l] = b;
         p.rem_in[l] = rem;
         rem -= b;
@@ -451,7 +455,8 @@ constexpr uint32_t EMIT_CAP = 256;          // solid hashes collected per wave b
 // EMIT: also append every solid hash to a list (emit_keys, capacity emit_cap, counter emit_n keeps counting
 // past the capacity so the host can tell a truncated list).  The list feeds the probe index
 // (brx_index.hpp) without a second pass over the 2^(2k-1)-bit vector.
-template <bool EMIT>
+// BITS: write the bucket's 512-byte slice of the bit vector (not for sparse sets: 2^(2k-1) bits do not fit at k = 21).
+template <bool EMIT, bool BITS>
 __global__ __launch_bounds__(64 * P3_WAVES) void final_count_kernel(const uint16_t *__restrict__ keys,
                                                                      const uint64_t *__restrict__ off, uint64_t n_buckets,
                                                                      uint32_t abundance, uint32_t *__restrict__ bits,
@@ -597,7 +602,8 @@ __global__ __launch_bounds__(64 * P3_WAVES) void final_count_kernel(const uint16
                 bmp[2 * lane] = 0;
                 bmp[2 * lane + 1] = 0;
             }
-            *reinterpret_cast<uint2 *>(dst + 2 * lane) = make_uint2(w0, w1);
+            if (BITS)
+                *reinterpret_cast<uint2 *>(dst + 2 * lane) = make_uint2(w0, w1);
             asm volatile("" ::: "memory");
             if (EMIT && any_bit) {
                 // one hash per lane and turn (slices hold a handful of bits: usually a single turn)
@@ -679,9 +685,11 @@ struct PartState {
     uint64_t *d_scan_tmp = nullptr;
     uint64_t scan_tmp_cap = 0;
     unsigned long long *d_scalars = nullptr; // [0] n_items, [1] total keys of the last scan
-    uint64_t *d_coff[MAX_LEVELS] = {nullptr, nullptr, nullptr}; // child offsets (nchild + 1)
-    uint32_t *d_keys_mid = nullptr;    // level-2 output when there are 3 levels
+    uint64_t *d_coff[MAX_LEVELS] = {nullptr, nullptr, nullptr, nullptr}; // child offsets (nchild + 1)
+    uint32_t *d_keys_mid = nullptr;    // outputs of the middle levels (ping-pong when there are 4 levels)
     uint64_t keys_mid_cap = 0;
+    uint32_t *d_keys_mid2 = nullptr;
+    uint64_t keys_mid2_cap = 0;
     uint16_t *d_keys_fin = nullptr;    // last level output
     uint64_t keys_fin_cap = 0;
     uint32_t *d_merged = nullptr;      // all batches merged per level-1 bucket (only when > 1 batch)
@@ -709,7 +717,11 @@ static int ensure_dev(void **p, uint64_t *cap, uint64_t need_bytes)
     return BRX_OK;
 }
 
-bool part_supported(int k) { return 2 * k - 1 > F_BITS && 2 * k - 1 - F_BITS <= MAX_LEVELS * MAX_DIGIT_BITS; }
+// level-1 keys are u32 with a digit of at most MAX_DIGIT_BITS stripped: hashes of up to 41 bits, k <= 21
+bool part_supported(int k)
+{
+    return 2 * k - 1 > F_BITS && 2 * k - 1 - F_BITS <= MAX_LEVELS * MAX_DIGIT_BITS && 2 * k - 1 - MAX_DIGIT_BITS <= 32;
+}
 
 int part_begin(brx_counter *c)
 {
@@ -749,7 +761,8 @@ void part_free(brx_counter *c)
         }
     for (void *p : {(void *)st->d_ntiles, (void *)st->d_item_off, (void *)st->d_item_parent, (void *)st->d_matrix,
                     (void *)st->d_pos, (void *)st->d_scan_tmp, (void *)st->d_scalars, (void *)st->d_coff[0],
-                    (void *)st->d_coff[1], (void *)st->d_coff[2], (void *)st->d_keys_mid, (void *)st->d_keys_fin,
+                    (void *)st->d_coff[1], (void *)st->d_coff[2], (void *)st->d_coff[3], (void *)st->d_keys_mid,
+                    (void *)st->d_keys_mid2, (void *)st->d_keys_fin,
                     (void *)st->d_merged, (void *)st->d_l1off_all, (void *)st->d_cnts, (void *)st->d_shift})
         if (p)
             (void)hipFree(p);
@@ -970,7 +983,14 @@ int part_finish_into(brx_counter *c, uint32_t abundance, hipStream_t s, brx_set 
     const uint32_t *keys1 = nullptr;
     const uint64_t *l1off = nullptr;
     if (st->batches.empty() || total == 0) {
-        BRX_HIP(hipMemsetAsync(dst->d_bits, 0, dst->nwords * 4, s));
+        if (dst->sparse) {
+            if (!dst->d_keylist_n)
+                BRX_HIP(hipMalloc((void **)&dst->d_keylist_n, 8));
+            BRX_HIP(hipMemsetAsync(dst->d_keylist_n, 0, 8, s));
+            dst->keylist_valid = true; // the empty list
+        } else {
+            BRX_HIP(hipMemsetAsync(dst->d_bits, 0, dst->nwords * 4, s));
+        }
         return BRX_OK;
     } else if (st->batches.size() == 1) {
         keys1 = st->batches[0].d_keys;
@@ -1002,9 +1022,10 @@ int part_finish_into(brx_counter *c, uint32_t abundance, hipStream_t s, brx_set 
     // solid-key list for the probe index: a solid hash was seen more than `abundance` times, so there are at
     // most total / (abundance + 1) of them; real data is far below that, and a list that turns out too short
     // is simply not used (the index is then built from the bit vector)
-    const bool emit = index_wanted(c->k);
+    const bool emit = dst->sparse || index_wanted(c->k);
     if (emit) {
-        const uint64_t div = abundance + 1u > 8u ? abundance + 1u : 8u;
+        // (a sparse set has nothing but this list: it gets the exact bound)
+        const uint64_t div = dst->sparse ? abundance + 1u : (abundance + 1u > 8u ? abundance + 1u : 8u);
         const uint64_t want = total / div + (1ull << 20);
         if (dst->keylist_cap < want || !dst->d_keylist) {
             if (dst->d_keylist)
@@ -1018,32 +1039,46 @@ int part_finish_into(brx_counter *c, uint32_t abundance, hipStream_t s, brx_set 
             BRX_HIP(hipMalloc((void **)&dst->d_keylist_n, 8));
         BRX_HIP(hipMemsetAsync(dst->d_keylist_n, 0, 8, s));
     }
-    const uint64_t *fin_off = nullptr;
-    if (pl.nlev == 2) {
-        BRX_TRY(run_level<uint16_t>(st, 1, keys1, l1off, pl.nchild[0], total, st->d_keys_fin, s, "part_l2_hist",
-                                    "part_l2_scatter"));
-        fin_off = st->d_coff[1];
-    } else {
+    // levels 2 .. nlev: u32 keys through one or two middle buffers, u16 out of the last level
+    static const char *hist_tag[MAX_LEVELS] = {"part_l1_hist", "part_l2_hist", "part_l3_hist", "part_l4_hist"};
+    static const char *scat_tag[MAX_LEVELS] = {"part_l1_scatter", "part_l2_scatter", "part_l3_scatter", "part_l4_scatter"};
+    if (pl.nlev >= 3) {
         uint64_t capb = st->keys_mid_cap;
         BRX_TRY(ensure_dev((void **)&st->d_keys_mid, &capb, (total + 64) * 4));
         st->keys_mid_cap = capb;
-        BRX_TRY(run_level<uint32_t>(st, 1, keys1, l1off, pl.nchild[0], total, st->d_keys_mid, s, "part_l2_hist",
-                                    "part_l2_scatter"));
-        BRX_TRY(run_level<uint16_t>(st, 2, st->d_keys_mid, st->d_coff[1], pl.nchild[1], total, st->d_keys_fin, s,
-                                    "part_l3_hist", "part_l3_scatter"));
-        fin_off = st->d_coff[2];
     }
+    if (pl.nlev >= 4) {
+        uint64_t capb = st->keys_mid2_cap;
+        BRX_TRY(ensure_dev((void **)&st->d_keys_mid2, &capb, (total + 64) * 4));
+        st->keys_mid2_cap = capb;
+    }
+    const uint32_t *kin = keys1;
+    const uint64_t *poff = l1off;
+    for (int l = 1; l < pl.nlev; l++) {
+        if (l == pl.nlev - 1) {
+            BRX_TRY(run_level<uint16_t>(st, l, kin, poff, pl.nchild[l - 1], total, st->d_keys_fin, s, hist_tag[l], scat_tag[l]));
+        } else {
+            uint32_t *kout = (l & 1) ? st->d_keys_mid : st->d_keys_mid2;
+            BRX_TRY(run_level<uint32_t>(st, l, kin, poff, pl.nchild[l - 1], total, kout, s, hist_tag[l], scat_tag[l]));
+            kin = kout;
+        }
+        poff = st->d_coff[l];
+    }
+    const uint64_t *fin_off = st->d_coff[pl.nlev - 1];
     {
         KernelTimer t("part_final_count", s);
         const uint64_t nb = pl.nchild[pl.nlev - 1];
         const uint64_t want_waves = nb < (256ull * 16ull * 8ull) ? nb : (256ull * 16ull * 8ull);
         const int grid = (int)((want_waves + P3_WAVES - 1) / P3_WAVES);
-        if (emit)
-            final_count_kernel<true><<<grid, 64 * P3_WAVES, 0, s>>>(st->d_keys_fin, fin_off, nb, abundance, dst->d_bits,
-                                                                   dst->d_keylist, dst->keylist_cap, dst->d_keylist_n);
+        if (dst->sparse)
+            final_count_kernel<true, false><<<grid, 64 * P3_WAVES, 0, s>>>(st->d_keys_fin, fin_off, nb, abundance, nullptr,
+                                                                          dst->d_keylist, dst->keylist_cap, dst->d_keylist_n);
+        else if (emit)
+            final_count_kernel<true, true><<<grid, 64 * P3_WAVES, 0, s>>>(st->d_keys_fin, fin_off, nb, abundance, dst->d_bits,
+                                                                         dst->d_keylist, dst->keylist_cap, dst->d_keylist_n);
         else
-            final_count_kernel<false><<<grid, 64 * P3_WAVES, 0, s>>>(st->d_keys_fin, fin_off, nb, abundance, dst->d_bits,
-                                                                    nullptr, 0, nullptr);
+            final_count_kernel<false, true><<<grid, 64 * P3_WAVES, 0, s>>>(st->d_keys_fin, fin_off, nb, abundance, dst->d_bits,
+                                                                          nullptr, 0, nullptr);
     }
     BRX_HIP(hipGetLastError());
     trace_stage(s, "final count");

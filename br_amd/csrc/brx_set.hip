@@ -291,7 +291,7 @@ int check_k(int k, bool need_odd)
     return BRX_OK;
 }
 
-int alloc_set(int k, int device, bool zero, brx_set **out)
+int alloc_set(int k, int device, bool zero, brx_set **out, bool sparse = false)
 {
     BRX_TRY(check_k(k, false));
     BRX_TRY(use_device(device));
@@ -300,6 +300,21 @@ int alloc_set(int k, int device, bool zero, brx_set **out)
     s->device = device;
     s->nwords = set_nwords(k);
     s->d_bits = nullptr;
+    s->sparse = sparse || sparse_k(k);
+    if (s->sparse) { // no bit vector: an empty key list is the empty set
+        s->nwords = 0;
+        hipError_t e = hipMalloc((void **)&s->d_keylist_n, 8);
+        if (e == hipSuccess)
+            e = hipMemset(s->d_keylist_n, 0, 8);
+        if (e != hipSuccess) {
+            set_error("sparse set alloc: %s", hipGetErrorString(e));
+            delete s;
+            return BRX_ERR_NOMEM;
+        }
+        s->keylist_valid = true;
+        *out = s;
+        return BRX_OK;
+    }
     hipError_t e = hipMalloc((void **)&s->d_bits, s->nwords * 4);
     if (e != hipSuccess) {
         set_error("hipMalloc(%llu B bitset, k=%d): %s", (unsigned long long)(s->nwords * 4), k, hipGetErrorString(e));
@@ -316,6 +331,15 @@ int alloc_set(int k, int device, bool zero, brx_set **out)
         }
     }
     *out = s;
+    return BRX_OK;
+}
+
+int need_bits(const brx_set *set, const char *what)
+{
+    if (set->sparse) {
+        set_error("%s needs the bit vector; a sparse set (k=%d) has none", what, set->k);
+        return BRX_ERR_UNSUPPORTED;
+    }
     return BRX_OK;
 }
 
@@ -406,6 +430,10 @@ int brx_set_new_from_solid_bytes(const uint8_t *buf, size_t len, int device, brx
                   (unsigned long long)((k >= 1 && k <= 31) ? set_nbytes_file(k) : 0));
         return BRX_ERR_FORMAT;
     }
+    if (sparse_k(k)) {
+        set_error(".solid stream with k=%d: sets of that size are sparse here (no bit vector)", k);
+        return BRX_ERR_UNSUPPORTED;
+    }
     brx_set *s = nullptr;
     BRX_TRY(alloc_set(k, device, set_nbytes_file(k) < 4, &s));
     hipError_t e = hipMemcpy(s->d_bits, buf + 1, len - 1, hipMemcpyHostToDevice);
@@ -425,6 +453,7 @@ int brx_set_insert_batch(brx_set_t *set, const uint8_t *bases, const uint64_t *o
         return BRX_ERR_ARG;
     }
     BRX_TRY(check_k(set->k, true));
+    BRX_TRY(need_bits(set, "insert_batch"));
     BRX_TRY(use_device(set->device));
     if (n_reads == 0)
         return BRX_OK;
@@ -455,6 +484,7 @@ int brx_set_set(brx_set_t *set, uint64_t forward_kmer, bool value)
 {
     if (!set)
         return BRX_ERR_ARG;
+    BRX_TRY(need_bits(set, "set"));
     BRX_TRY(use_device(set->device));
     index_invalidate(set);
     const uint64_t h = khash(forward_kmer & kmask(set->k), set->k);
@@ -467,6 +497,10 @@ bool brx_set_get(const brx_set_t *set, uint64_t forward_kmer)
 {
     if (!set || use_device(set->device) != BRX_OK)
         return false;
+    if (set->sparse) {
+        uint8_t o = 0;
+        return brx_set_get_batch(set, &forward_kmer, 1, &o) == BRX_OK && o;
+    }
     const uint64_t h = khash(forward_kmer & kmask(set->k), set->k);
     uint32_t w = 0;
     if (hipMemcpy(&w, set->d_bits + (h >> 5), 4, hipMemcpyDeviceToHost) != hipSuccess)
@@ -481,6 +515,10 @@ int brx_set_get_batch(const brx_set_t *set, const uint64_t *forward_kmers, uint3
     BRX_TRY(use_device(set->device));
     if (!n)
         return BRX_OK;
+    if (set->sparse) { // the probe index is all there is
+        BRX_TRY(index_ensure(set, nullptr));
+        return brx_set_get_batch_indexed(set, forward_kmers, n, out, nullptr);
+    }
     uint64_t *d_k = nullptr;
     uint8_t *d_o = nullptr;
     BRX_HIP(hipMalloc((void **)&d_k, (uint64_t)n * 8));
@@ -512,6 +550,7 @@ int brx_set_export_solid_bytes(const brx_set_t *set, uint8_t *buf, size_t cap, s
 {
     if (!set || !len)
         return BRX_ERR_ARG;
+    BRX_TRY(need_bits(set, "export (.solid)"));
     const size_t need = 1 + (size_t)set_nbytes_file(set->k);
     *len = need;
     if (!buf || cap < need) {
@@ -529,6 +568,17 @@ int brx_set_popcount(const brx_set_t *set, uint64_t *n_set_bits)
     if (!set || !n_set_bits)
         return BRX_ERR_ARG;
     BRX_TRY(use_device(set->device));
+    if (set->sparse) {
+        if (set->idx_valid) {
+            *n_set_bits = set->idx_keys;
+            return BRX_OK;
+        }
+        unsigned long long nl = 0;
+        if (set->keylist_valid)
+            BRX_HIP(hipMemcpy(&nl, set->d_keylist_n, 8, hipMemcpyDeviceToHost));
+        *n_set_bits = nl;
+        return BRX_OK;
+    }
     unsigned long long *d_t = nullptr;
     BRX_HIP(hipMalloc((void **)&d_t, 8));
     BRX_HIP(hipMemset(d_t, 0, 8));
@@ -548,10 +598,13 @@ int brx_set_device_bits(const brx_set_t *set, void **d_bits, uint64_t *n_bytes)
 {
     if (!set || !d_bits || !n_bytes)
         return BRX_ERR_ARG;
+    BRX_TRY(need_bits(set, "device_bits"));
     *d_bits = set->d_bits;
     *n_bytes = set->nwords * 4;
     return BRX_OK;
 }
+
+int brx_set_sparse(const brx_set_t *set) { return set && set->sparse ? 1 : 0; }
 
 void brx_set_free(brx_set_t *set)
 {
@@ -709,6 +762,7 @@ int brx_set_count_finish_into(brx_counter_t *c, uint8_t abundance, void *stream,
     hipStream_t s = (hipStream_t)stream; // nullptr = the legacy default stream, like any HIP API
     if (c->strategy == BRX_COUNT_SORTED)
         return part_finish_into(c, abundance, s, dst);
+    BRX_TRY(need_bits(dst, "the dense count strategy"));
     {
         KernelTimer t("threshold", s);
         threshold_kernel<<<grid_for(dst->nwords, 256, 256 * 16), 256, 0, s>>>((const uint4 *)c->d_counts, dst->nwords,
@@ -723,7 +777,8 @@ int brx_set_count_finish(brx_counter_t *c, uint8_t abundance, void *stream, brx_
     if (!c || !out)
         return BRX_ERR_ARG;
     brx_set *set = nullptr;
-    BRX_TRY(alloc_set(c->k, c->device, false, &set));
+    const char *fs = getenv("BRX_FORCE_SPARSE"); // tests: the sparse representation at small k
+    BRX_TRY(alloc_set(c->k, c->device, false, &set, fs && *fs == '1' && c->strategy == BRX_COUNT_SORTED));
     int st = brx_set_count_finish_into(c, abundance, stream, set);
     if (st == BRX_OK) {
         hipError_t e = hipStreamSynchronize((hipStream_t)stream);
@@ -829,6 +884,7 @@ int brx_set_extract_keys_device(const brx_set_t *set, uint64_t first_hash, uint6
         set_error("null argument");
         return BRX_ERR_ARG;
     }
+    BRX_TRY(need_bits(set, "extract_keys (use brx_set_keylist_device)"));
     const uint64_t nbits = set->nwords * 32;
     if ((first_hash & 127u) || (n_hashes & 31u) || first_hash + n_hashes > nbits) {
         set_error("extract range must start on a multiple of 128 hashes, span a multiple of 32, and lie inside the set");
@@ -866,6 +922,7 @@ int brx_set_or_keys_device(brx_set_t *set, const uint64_t *d_keys, uint64_t n, v
 {
     if (!set || (!d_keys && n))
         return BRX_ERR_ARG;
+    BRX_TRY(need_bits(set, "or_keys (use brx_set_index_build_from_keys_device)"));
     BRX_TRY(use_device(set->device));
     if (!n)
         return BRX_OK;

@@ -143,6 +143,10 @@ class Pcon(KmerSet):
         _lib.check(L.brx_set_export_solid_bytes(self._h, buf.ctypes.data, buf.size, C.byref(n)))
         return buf[1:]
 
+    def is_sparse(self) -> bool:
+        """k >= 21: no bit vector, the solid k-mers live in the key list / probe index only (include/brx.h)"""
+        return bool(_lib.lib().brx_set_sparse(self._h))
+
     def popcount(self) -> int:
         n = C.c_uint64(0)
         _lib.check(_lib.lib().brx_set_popcount(self._h, C.byref(n)))

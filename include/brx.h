@@ -96,6 +96,12 @@ int brx_set_device(const brx_set_t *set);
 /* .solid writer ([k][bits]); len = 1 + 2^(2k-4) (at least 2)                               */
 int brx_set_export_solid_bytes(const brx_set_t *set, uint8_t *buf, size_t cap, size_t *len);
 int brx_set_popcount(const brx_set_t *set, uint64_t *n_set_bits);
+/* 1 for a SPARSE set: k >= 21, where the 2^(2k-1)-bit vector (256 GiB at k = 21) does not fit next to the data.
+ * Such a set holds its solid k-mers only as a key list and as the probe index (exact, overflowing lines chain
+ * into the next line).  get / get_batch / popcount / count_finish[_into] / the correction entry points work;
+ * entries that need the bit vector (.solid import/export, set, insert_batch, device_bits, extract/or_keys)
+ * return BRX_ERR_UNSUPPORTED.  Sets are built by the partitioned counter (k <= 21).                          */
+int brx_set_sparse(const brx_set_t *set);
 /* device view of the packed bit array (for RCCL all-gather / OR across ranks)              */
 int brx_set_device_bits(const brx_set_t *set, void **d_bits, uint64_t *n_bytes);
 /* sparse replication of the set: list the set bits of [first_hash, first_hash+n_hashes) (both

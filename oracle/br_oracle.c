@@ -196,6 +196,10 @@ typedef struct {
     int k;
     uint64_t nbits;
     uint8_t *bits;
+    /* sparse variant for k where 2^(2k-1) bits do not fit a test machine (k = 21: 256 GiB): the same set as a
+     * sorted array of canonical hashes; `get` is a binary search.  Checked against the bitset at small k.    */
+    uint64_t *sorted;
+    size_t n_sorted;
 } bro_solid;
 
 uint64_t bro_solid_nbytes(int k)
@@ -217,11 +221,28 @@ bro_solid *bro_solid_new(int k)
     return s;
 }
 
+/* `hashes` = canonical hashes (bro_hash), sorted ascending, unique */
+bro_solid *bro_solid_new_sparse(int k, const uint64_t *hashes, size_t n)
+{
+    bro_solid *s = (bro_solid *)calloc(1, sizeof(bro_solid));
+    s->k = k;
+    s->nbits = (2 * k - 1 >= 64) ? 0 : (1ull << (2 * k - 1));
+    s->sorted = (uint64_t *)malloc((n ? n : 1) * sizeof(uint64_t));
+    if (!s->sorted) {
+        free(s);
+        return NULL;
+    }
+    memcpy(s->sorted, hashes, n * sizeof(uint64_t));
+    s->n_sorted = n;
+    return s;
+}
+
 void bro_solid_free(bro_solid *s)
 {
     if (!s)
         return;
     free(s->bits);
+    free(s->sorted);
     free(s);
 }
 
@@ -247,11 +268,24 @@ void bro_solid_set(bro_solid *s, uint64_t kmer, int val)
 int bro_solid_get(const bro_solid *s, uint64_t kmer)
 {
     uint64_t h = bro_hash(kmer, s->k);
+    if (s->sorted) {
+        size_t lo = 0, hi = s->n_sorted;
+        while (lo < hi) {
+            size_t mid = lo + (hi - lo) / 2;
+            if (s->sorted[mid] < h)
+                lo = mid + 1;
+            else
+                hi = mid;
+        }
+        return lo < s->n_sorted && s->sorted[lo] == h;
+    }
     return (s->bits[h >> 3] >> (h & 7)) & 1;
 }
 
 uint64_t bro_solid_popcount(const bro_solid *s)
 {
+    if (s->sorted)
+        return s->n_sorted;
     uint64_t n = 0, nb = bro_solid_nbytes(s->k);
     for (uint64_t i = 0; i < nb; i++)
         n += (uint64_t)__builtin_popcount(s->bits[i]);

@@ -58,6 +58,7 @@ def lib():
         "bro_solid_popcount": (C.c_uint64, [vp]),
         "bro_solid_set_seq": (None, [vp, C.c_char_p, C.c_size_t]),
         "bro_solid_from_count": (vp, [C.c_int, vp, C.c_uint8]),
+        "bro_solid_new_sparse": (vp, [C.c_int, vp, C.c_size_t]),
         "bro_solid_from_bytes": (vp, [C.c_char_p, C.c_size_t]),
         "bro_solid_wrap": (vp, [C.c_int, vp]),
         "bro_solid_unwrap": (None, [vp]),
@@ -162,6 +163,18 @@ class Solid:
         counts = np.ascontiguousarray(counts, dtype=np.uint8)
         assert counts.size == L.bro_count_nbytes(k)
         h = L.bro_solid_from_count(k, counts.ctypes.data, abundance)
+        return cls(k, _h=h)
+
+    @classmethod
+    def sparse_from_count(cls, k: int, reads, abundance: int) -> "Solid":
+        """the same set as from_count(k, count_reads(k, reads), abundance), held as a sorted array of canonical
+        hashes instead of 2^(2k-1) bits (k = 21 would need 256 GiB): count every canonical k-mer of every read
+        (saturating at 255 like the u8 counter), keep those with count > abundance."""
+        parts = [hashes(k, r) for r in reads if len(r) >= k]
+        allh = np.concatenate(parts) if parts else np.zeros(0, dtype=np.uint64)
+        uniq, cnt = np.unique(allh, return_counts=True)
+        keep = np.ascontiguousarray(uniq[np.minimum(cnt, 255) > abundance], dtype=np.uint64)
+        h = lib().bro_solid_new_sparse(k, keep.ctypes.data, keep.size)
         return cls(k, _h=h)
 
     @classmethod

@@ -139,3 +139,21 @@ def test_bio_global_basics():
     assert ops.count("I") == 1 and ops.count("D") == 0 and len(ops) == 5
     ops = O.bio_global(b"ACGT", b"ACGTT")
     assert ops.count("D") == 1 and ops.count("I") == 0
+
+
+def test_sparse_solid_equals_bitset_solid(raw_reads):
+    """the sparse oracle set (sorted hashes; needed at k=21 where the bit vector is 256 GiB) is the same set as
+    the pinned bitset one, and every corrector gives the same bytes with either"""
+    for k, a in ((11, 2), (13, 1), (15, 0)):
+        dense = O.Solid.from_count(k, O.count_reads(k, raw_reads), a)
+        sparse = O.Solid.sparse_from_count(k, raw_reads, a)
+        assert sparse.popcount() == dense.popcount()
+        rng = np.random.default_rng(k)
+        q = np.concatenate([O.hashes(k, raw_reads[0])[:500] * 2, rng.integers(0, 1 << (2 * k), 500, dtype=np.uint64)])
+        for x in q:
+            assert sparse.get(int(x)) == dense.get(int(x))
+    for method in ("one", "two", "graph", "greedy", "gap_size"):
+        md = O.build_methods(dense, [method], 5, 7)
+        ms = O.build_methods(sparse, [method], 5, 7)
+        for r in raw_reads[:12]:
+            assert O.correct_record(md, r, False) == O.correct_record(ms, r, False)
