@@ -9,8 +9,8 @@ Same flags, defaults and quirks as the reference: `-s/--two-side` DISABLES the r
 (src/lib.rs:48,110); `fasta -k` is forced odd (src/cli.rs:277-279); without `-a` an abundance method
 sub-command is needed (src/main.rs:95-110).  `first-minimum` is implemented from pcon's published
 algorithm (first index where the count spectrum rises; unpinned by the reference's tests);
-`rarefaction` / `percent-most` / `percent-least`, the `count` sub-command (pcon count files) and
-`large-kmer` (hash set, k <= 32) are rows N2-N4 of SURVEY 8(f) and fail loudly here.  `-t` (rayon
+`rarefaction` / `percent-most` / `percent-least` and the `count` sub-command (pcon count files) are rows
+N2-N3 of SURVEY 8(f) and fail loudly here; `large-kmer -f fasta` (N4) builds a sparse set for odd k <= 31.  `-t` (rayon
 pool size) is accepted and ignored: the GPU is the pool.
 """
 from __future__ import annotations
@@ -142,7 +142,13 @@ def build_set(args) -> Pcon:
         return Pcon.from_fasta(_records([args.sub_input]), args.kmer_size, dev)
     if args.subcommand == "count":
         raise SystemExit("the pcon count-file format is not implemented on the HIP path (unpinned, SURVEY 8(f) N3)")
-    raise SystemExit("large-kmer (hash set) mode is not implemented on the HIP path (SURVEY 8(f) N4)")
+    # large-kmer -f fasta: set::Hash::from_fasta (src/set/hash.rs:40-60, src/main.rs:147-163) = every canonical k-mer of
+    # every record, no counting.  Same membership as a presence-only Pcon; for k >= 21 the set is sparse (a chained
+    # hash table in HBM instead of the bit vector).  Odd k only: cocktail's parity-canonical form is not a function
+    # of the {k-mer, revcomp} pair for even k.
+    if args.kmer_size % 2 == 0 or not 1 <= args.kmer_size <= 31:
+        raise SystemExit("Error: large-kmer mode needs an odd k <= 31 on the HIP path (k=%d)" % args.kmer_size)
+    return Pcon.from_fasta(_records([args.sub_input]), args.kmer_size, dev)
 
 
 def main(argv: Optional[List[str]] = None) -> int:

@@ -72,6 +72,54 @@ __global__ void index_get_kernel(IdxView v, const uint32_t *__restrict__ bits, c
     out[i] = (uint8_t)r;
 }
 
+// presence-only fill of a sparse set: every k-mer of every read of length >= k (Hash::from_fasta, src/set/hash.rs:40-60)
+constexpr int INS_STRIP = 32;
+__global__ __launch_bounds__(256) void table_insert_reads_kernel(const uint8_t *__restrict__ bases, const uint64_t *__restrict__ offsets,
+                                                                 uint32_t n_reads, int k, uint64_t *__restrict__ lines, uint32_t line_shift,
+                                                                 uint32_t m, uint32_t w, unsigned long long *__restrict__ n_new)
+{
+    const uint64_t mask = kmask(k);
+    uint32_t added = 0;
+    for (uint32_t r = blockIdx.x; r < n_reads; r += gridDim.x) {
+        const uint64_t s = offsets[r];
+        const uint64_t len = offsets[r + 1] - s;
+        if (len < (uint64_t)k)
+            continue;
+        const uint64_t nk = len - (uint64_t)k + 1;
+        const uint8_t *seq = bases + s;
+        for (uint64_t p0 = (uint64_t)threadIdx.x * INS_STRIP; p0 < nk; p0 += (uint64_t)blockDim.x * INS_STRIP) {
+            uint64_t kmer = 0;
+            for (int j = 0; j < k; j++)
+                kmer = (kmer << 2) | nuc2bit(seq[p0 + j]);
+            const uint64_t pend = (p0 + INS_STRIP < nk) ? p0 + INS_STRIP : nk;
+            for (uint64_t p = p0;;) {
+                added += table_find_or_insert(lines, line_shift, m, w, k, kmer) ? 1u : 0u;
+                if (++p >= pend)
+                    break;
+                kmer = add_nuc(kmer, nuc2bit(seq[p + k - 1]), mask);
+            }
+        }
+    }
+    for (int d = 32; d > 0; d >>= 1)
+        added += __shfl_down(added, d);
+    if ((threadIdx.x & 63) == 0 && added)
+        atomicAdd(n_new, (unsigned long long)added);
+}
+
+// moves every key of one table into another (growing an insert-built set)
+__global__ __launch_bounds__(256) void table_rehash_kernel(const uint64_t *__restrict__ old_lines, uint64_t n_old_lines, int k,
+                                                           uint64_t *__restrict__ lines, uint32_t line_shift, uint32_t m, uint32_t w)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_old_lines * IDX_SLOTS; i += stride) {
+        const uint64_t v = old_lines[(i / IDX_SLOTS) * 8ull + (i % IDX_SLOTS)];
+        if (v) {
+            const uint64_t h = v - 1ull;
+            (void)table_find_or_insert(lines, line_shift, m, w, k, (h << 1) | (uint64_t)(popc64(h) & 1));
+        }
+    }
+}
+
 int env_int(const char *name, int dflt)
 {
     const char *e = getenv(name);
@@ -101,10 +149,8 @@ int index_auto_m(int k, uint64_t n_keys)
         m += 2;
     if (m > k - 2)
         m = k - 2;
-    if (k - m + 1 > 16)
-        m = k - 15;
     if (!(m & 1))
-        m++;
+        m--;
     return m < 3 ? 3 : m;
 }
 
@@ -120,8 +166,8 @@ static int index_build_locked(brx_set *set, const uint64_t *d_keys, uint64_t n, 
         m = env_int("BRX_INDEX_M", 0);
     if (m <= 0)
         m = index_auto_m(k, n);
-    if (!(m & 1) || m < 3 || m > IDX_MAX_M || k - m + 1 < 2 || k - m + 1 > 16) {
-        set_error("probe index: minimizer length %d must be odd, 3..%d, with 2..16 windows in a %d-mer", m, IDX_MAX_M, k);
+    if (!(m & 1) || m < 3 || m > IDX_MAX_M || k - m + 1 < 2) {
+        set_error("probe index: minimizer length %d must be odd, 3..%d and shorter than the %d-mer", m, IDX_MAX_M, k);
         return BRX_ERR_ARG;
     }
     if (log_lines <= 0)
@@ -188,6 +234,7 @@ static int index_build_locked(brx_set *set, const uint64_t *d_keys, uint64_t n, 
     set->idx_keys = n;
     set->idx_overflow_keys = ovf;
     set->idx_exact = set->sparse;
+    set->idx_open = false;
     set->idx_valid = true;
     return BRX_OK;
 }
@@ -196,6 +243,90 @@ int index_build_from_keys(brx_set *set, const uint64_t *d_keys, uint64_t n, int 
 {
     std::lock_guard<std::mutex> g(set->idx_mu);
     return index_build_locked(set, d_keys, n, m, log_lines, s);
+}
+
+// presence-only insertion into a sparse set (the table IS the set; kept at most ~half full, regrown by rehashing)
+int index_insert_reads(brx_set *set, const uint8_t *d_bases, const uint64_t *d_offsets, uint32_t n_reads, uint64_t total_bases,
+                       hipStream_t s)
+{
+    const int k = set->k;
+    if (!set->sparse || !(k & 1) || k < 5 || k > 31) {
+        set_error("k-mer insertion into a sparse set needs an odd 5 <= k <= 31 (k=%d%s)", k, set->sparse ? "" : ", set is not sparse");
+        return BRX_ERR_UNSUPPORTED;
+    }
+    BRX_TRY(use_device(set->device));
+    std::lock_guard<std::mutex> g(set->idx_mu);
+    if (set->idx_valid && !set->idx_open) {
+        set_error("the set was built by counting; k-mers cannot be added to it");
+        return BRX_ERR_UNSUPPORTED;
+    }
+    if (!set->idx_valid) { // the empty set
+        set->idx_keys = 0;
+        set->idx_overflow_keys = 0;
+    }
+    const uint64_t need = set->idx_keys + total_bases; // every k-mer of the batch could be new
+    const bool have = set->idx_valid && set->d_lines;
+    if (!have || (7ull << set->idx_log_lines) < 2ull * need) {
+        int log_lines = 12;
+        while (log_lines < 30 && (7ull << log_lines) < 3ull * need)
+            log_lines++;
+        if ((7ull << log_lines) < need + need / 4) {
+            set_error("sparse set: %llu k-mers do not fit the largest table", (unsigned long long)need);
+            return BRX_ERR_NOMEM;
+        }
+        int m = env_int("BRX_INDEX_M", 0);
+        if (m <= 0)
+            m = index_auto_m(k, need);
+        if (!(m & 1) || m < 3 || m > IDX_MAX_M || m > k - 1) {
+            set_error("probe index: bad minimizer length %d for k=%d", m, k);
+            return BRX_ERR_ARG;
+        }
+        uint64_t *nl = nullptr;
+        hipError_t e = hipMalloc((void **)&nl, (64ull << log_lines));
+        if (e != hipSuccess) {
+            set_error("hipMalloc(%llu B sparse set table): %s", (unsigned long long)(64ull << log_lines), hipGetErrorString(e));
+            return BRX_ERR_NOMEM;
+        }
+        BRX_HIP(hipMemsetAsync(nl, 0, 64ull << log_lines, s));
+        if (have && set->idx_keys) {
+            KernelTimer t("index_rehash", s);
+            table_rehash_kernel<<<256 * 8, 256, 0, s>>>(set->d_lines, 1ull << set->idx_log_lines, k, nl, 32u - (uint32_t)log_lines,
+                                                        (uint32_t)m, (uint32_t)(k - m + 1));
+        }
+        BRX_HIP(hipStreamSynchronize(s));
+        if (set->d_lines)
+            (void)hipFree(set->d_lines);
+        set->d_lines = nl;
+        set->lines_alloc = 1ull << log_lines;
+        set->idx_log_lines = (uint32_t)log_lines;
+        set->idx_m = (uint32_t)m;
+    }
+    unsigned long long *d_new = nullptr;
+    BRX_HIP(hipMalloc((void **)&d_new, 8));
+    hipError_t e = hipMemsetAsync(d_new, 0, 8, s);
+    if (e == hipSuccess && n_reads) {
+        KernelTimer t("index_insert_reads", s);
+        const uint32_t grid = n_reads < (1u << 16) ? n_reads : (1u << 16);
+        table_insert_reads_kernel<<<grid, 256, 0, s>>>(d_bases, d_offsets, n_reads, k, set->d_lines, 32u - set->idx_log_lines,
+                                                       set->idx_m, (uint32_t)k - set->idx_m + 1u, d_new);
+        e = hipGetLastError();
+    }
+    unsigned long long added = 0;
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(&added, d_new, 8, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess)
+        e = hipStreamSynchronize(s);
+    (void)hipFree(d_new);
+    if (e != hipSuccess) {
+        set_error("sparse set insert: %s", hipGetErrorString(e));
+        return BRX_ERR_HIP;
+    }
+    set->idx_keys += added;
+    set->idx_exact = true;
+    set->idx_open = true;
+    set->idx_valid = true;
+    set->keylist_valid = false; // the table is the set now
+    return BRX_OK;
 }
 
 int index_ensure(const brx_set *cset, hipStream_t s)

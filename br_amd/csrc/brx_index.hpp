@@ -26,7 +26,7 @@ struct IdxView {
     const uint64_t *lines; // nullptr: no index, probe the bitset
     uint32_t line_shift;   // 32 - log2(number of lines)
     uint32_t m;            // minimizer length (odd, <= 15)
-    uint32_t w;            // k - m + 1 windows (2..16)
+    uint32_t w;            // k - m + 1 windows
 };
 
 #if defined(__HIPCC__)
@@ -69,7 +69,18 @@ __device__ __forceinline__ uint32_t minimizer_of(uint64_t fwd, uint64_t rc, uint
     case 13: return minimizer_hash_w<13>(fwd, rc, mm);
     case 14: return minimizer_hash_w<14>(fwd, rc, mm);
     case 15: return minimizer_hash_w<15>(fwd, rc, mm);
-    default: return minimizer_hash_w<16>(fwd, rc, mm);
+    case 16: return minimizer_hash_w<16>(fwd, rc, mm);
+    default: { // more than 16 windows (k >= 31 with m = 15): 64-bit shifts
+        uint32_t best = 0xffffffffu;
+        for (uint32_t j = 0; j < w; j++) {
+            const uint32_t f = (uint32_t)(fwd >> (2u * j)) & mm;
+            const uint32_t r = (uint32_t)(rc >> (2u * (w - 1u - j))) & mm;
+            const uint32_t c = f < r ? f : r;
+            const uint32_t h = c * 0x9E3779B1u;
+            best = h < best ? h : best;
+        }
+        return best;
+    }
     }
 }
 
@@ -92,6 +103,31 @@ __device__ __forceinline__ int index_probe(const IdxView &v, uint64_t fwd, int k
     // the line only for the lanes that did not match it -- a second, dependent memory round trip
     const bool found = (q0.x == key) | (q0.y == key) | (q1.x == key) | (q1.y == key) | (q2.x == key) | (q2.y == key) | (q3.x == key);
     return found ? 1 : ((q3.y & IDX_OVERFLOW) ? 2 : 0);
+}
+// find-or-insert of one k-mer into a chained table (sparse sets filled k-mer by k-mer, `br large-kmer`): true if the
+// key was not there.  Threads race for the first empty slot of a line with a CAS; slots never empty again, so
+// all threads see the same first empty slot and a key cannot land twice.
+__device__ __forceinline__ bool table_find_or_insert(uint64_t *lines, uint32_t line_shift, uint32_t m, uint32_t w, int k, uint64_t fwd)
+{
+    const uint64_t rc = revcomp(fwd, k);
+    const unsigned long long key = (((popc64(fwd) & 1) ? rc : fwd) >> 1) + 1ull;
+    const uint32_t line_mask = 0xffffffffu >> line_shift;
+    uint32_t line = index_line_of(minimizer_of(fwd, rc, m, w), line_shift);
+    for (;;) {
+        unsigned long long *L = reinterpret_cast<unsigned long long *>(lines) + (uint64_t)line * 8ull;
+        for (int j = 0; j < IDX_SLOTS; j++) {
+            unsigned long long v = __hip_atomic_load(L + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (v == 0ull)
+                v = atomicCAS(L + j, 0ull, key);
+            if (v == 0ull)
+                return true;
+            if (v == key)
+                return false;
+        }
+        if (!(__hip_atomic_load(L + 7, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & IDX_OVERFLOW))
+            atomicOr(L + 7, (unsigned long long)IDX_OVERFLOW);
+        line = (line + 1u) & line_mask; // the table is kept at most half full: this ends
+    }
 }
 #endif
 

@@ -67,6 +67,7 @@ struct brx_set {
     // index only, whose overflowing lines then chain into the next line instead of falling back to the bits
     bool sparse;
     bool idx_exact;          // the index was built with chaining (answers without the bit vector)
+    bool idx_open;           // ... and k-mer by k-mer (brx_set_insert_batch on a sparse set): more can be added
     // probe index over the same set (brx_index.hpp): built on demand, invalidated by every mutation
     // of the bits that goes through the ABI
     uint64_t *d_lines;       // 8 u64 per line
@@ -88,6 +89,8 @@ namespace brx {
 struct IdxView;
 // (re)builds the index from a device list of keys (bit indices = canonical >> 1); m / log_lines 0 = auto
 int index_build_from_keys(brx_set *set, const uint64_t *d_keys, uint64_t n, int m, int log_lines, hipStream_t s);
+int index_insert_reads(brx_set *set, const uint8_t *d_bases, const uint64_t *d_offsets, uint32_t n_reads, uint64_t total_bases,
+                       hipStream_t s);
 // sets of this k have no bit vector
 inline bool sparse_k(int k) { return k >= 21; }
 // builds the index from the bitset when the set has none (no-op for k outside the indexed range)

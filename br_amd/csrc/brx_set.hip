@@ -453,10 +453,22 @@ int brx_set_insert_batch(brx_set_t *set, const uint8_t *bases, const uint64_t *o
         return BRX_ERR_ARG;
     }
     BRX_TRY(check_k(set->k, true));
-    BRX_TRY(need_bits(set, "insert_batch"));
     BRX_TRY(use_device(set->device));
     if (n_reads == 0)
         return BRX_OK;
+    if (set->sparse) { // Hash::from_fasta (src/set/hash.rs:40-60): straight into the chained table
+        uint8_t *d_b = nullptr;
+        uint64_t *d_o = nullptr;
+        uint64_t bc = 0, oc = 0, tot = 0;
+        int st = upload_batch(bases, offsets, n_reads, &d_b, &bc, &d_o, &oc, &tot, 0);
+        if (st == BRX_OK)
+            st = index_insert_reads(set, d_b, d_o, n_reads, tot, 0);
+        if (d_b)
+            (void)hipFree(d_b);
+        if (d_o)
+            (void)hipFree(d_o);
+        return st;
+    }
     index_invalidate(set);
     uint8_t *d_b = nullptr;
     uint64_t *d_o = nullptr;

@@ -117,3 +117,41 @@ def test_k21_synthetic_properties_and_oracle_sample():
         got = br_amd.Chain(gs, [(m, 5, 7) for m in names], two_side=False).correct_reads([reads[i] for i in sample])
         for i, gseq in zip(sample, got):
             assert gseq == O.correct_record(om, reads[i], False), (names, i)
+
+
+@pytest.mark.parametrize("k", [21, 25, 31])
+def test_large_kmer_presence_set_vs_oracle(raw_reads, k):
+    """`br large-kmer -f fasta -k K` (set::Hash::from_fasta, src/set/hash.rs:40-60): every canonical k-mer of every
+    record, inserted k-mer by k-mer into the chained table (several batches, so the table regrows); membership and
+    every corrector against the sparse oracle with the same presence semantics (count > 0)."""
+    trusted = raw_reads[:60]
+    gs = br_amd.Pcon.from_fasta(trusted, k, batch=16)
+    assert gs.is_sparse()
+    ref = O.Solid.sparse_from_count(k, trusted, 0)
+    assert gs.popcount() == ref.popcount() > 10_000
+    q = _queries(k, trusted, np.random.default_rng(k))
+    want = np.array([ref.get(int(x)) for x in q])
+    assert np.array_equal(gs.get_many(q), want)
+    # correct OTHER reads (and the trusted ones) against the presence set
+    reads = raw_reads[40:100]
+    for method in METHODS:
+        om = O.build_methods(ref, [method], 5, 7)
+        sub = reads[:25] if method == "greedy" else reads
+        got = br_amd.Chain(gs, [(method, 5, 7)], two_side=False).correct_reads(sub)
+        for r, g in zip(sub, got):
+            assert g == O.correct_record(om, r, False), (k, method)
+
+
+def test_large_kmer_cli(tmp_path, golden_dir, raw_reads):
+    import os
+    from br_amd import cli
+    src = os.path.join(golden_dir, "raw.fasta")
+    dst = tmp_path / "corr.fasta"
+    assert cli.main(["-i", src, "-o", str(dst), "-c", "one", "-s", "large-kmer", "-i", src, "-f", "fasta", "-k", "23"]) == 0
+    ref = O.Solid.sparse_from_count(23, raw_reads, 0)
+    # every k-mer of the input is in the set: nothing triggers, the reads come back unchanged (wrapped at 80 columns)
+    from br_amd import fasta
+    got = [seq for _, _, seq in fasta.read_records(open(dst, "rb"))]
+    assert got == raw_reads and ref.popcount() > 0
+    with pytest.raises(SystemExit):
+        cli.main(["-i", src, "-o", str(dst), "large-kmer", "-i", src, "-f", "fasta", "-k", "24"])
