@@ -59,6 +59,7 @@ SIGNATURES = {
     "brx_set_export_solid_bytes": (C.c_int, [_vp, _vp, C.c_size_t, C.POINTER(C.c_size_t)]),
     "brx_set_popcount": (C.c_int, [_vp, _u64p]),
     "brx_set_sparse": (C.c_int, [_vp]),
+    "brx_set_bits_state": (C.c_int, [_vp]),
     "brx_set_device_bits": (C.c_int, [_vp, _pp, _u64p]),
     "brx_set_extract_keys_device": (C.c_int, [_vp, C.c_uint64, C.c_uint64, _vp, C.c_uint64, _u64p, _vp]),
     "brx_set_or_keys_device": (C.c_int, [_vp, _vp, C.c_uint64, _vp]),

@@ -1394,10 +1394,17 @@ int brx_chain_correct_batch_device(brx_chain_t *ch, const uint8_t *d_bases, cons
         ch->scan_tmp_cap = tmp_bytes;
     }
 
+    // walks (Two/Graph/Greedy/GapSize forward passes) are faster on the bit vector: materialise a lazy one now
+    if (ch->set->bits_stale && !ch->set->sparse)
+        for (const brx_method_t &md : ch->methods)
+            if (md.method != BRX_ONE) {
+                BRX_TRY(ensure_bits(ch->set, s, "correction"));
+                break;
+            }
     // probe index of the set (built here when the set has none yet, e.g. after a finish_into)
     BRX_TRY(index_ensure(ch->set, s));
     IdxView idx{nullptr, 0, 0, 0};
-    if (ch->set->idx_valid && (index_wanted(k) || ch->set->sparse))
+    if (ch->set->idx_valid && (index_wanted(k) || no_bits(ch->set)))
         idx = IdxView{ch->set->d_lines, 32u - ch->set->idx_log_lines, ch->set->idx_m, (uint32_t)k - ch->set->idx_m + 1u};
 
     const int n_dirs = ch->two_side ? 1 : 2;
@@ -1441,12 +1448,12 @@ int brx_chain_correct_batch_device(brx_chain_t *ch, const uint8_t *d_bases, cons
         for (int dir = 0; dir < n_dirs && !any_overflow; dir++) {
             for (int m = 0; m < n_methods; m++) {
                 PassParams p;
-                p.bits = ch->set->d_bits;
+                p.bits = no_bits(ch->set) ? nullptr : ch->set->d_bits;
                 // the index pays where whole groups probe neighbouring k-mers: One's passes and the (nearly
                 // trigger-free) reverse scans.  Walks probe 4 successors of one k-mer per round: measured
                 // 10-15 % slower through the index (Graph, GapSize forward), Greedy 78 % slower.
                 const int mth = ch->methods[m].method;
-                const bool use_idx = ch->set->sparse || mth == BRX_ONE || (dir == 1 && mth != BRX_GREEDY);
+                const bool use_idx = no_bits(ch->set) || mth == BRX_ONE || (dir == 1 && mth != BRX_GREEDY);
                 p.idx = use_idx ? idx : IdxView{nullptr, 0, 0, 0};
                 p.k = k;
                 p.c = ch->methods[m].confirm;

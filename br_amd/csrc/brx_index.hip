@@ -120,6 +120,29 @@ __global__ __launch_bounds__(256) void table_rehash_kernel(const uint64_t *__res
     }
 }
 
+__global__ __launch_bounds__(256) void table_to_bits_kernel(const uint64_t *__restrict__ lines, uint64_t n_lines, uint32_t *__restrict__ bits,
+                                                            uint64_t nbits)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_lines * IDX_SLOTS; i += stride) {
+        const uint64_t v = lines[(i / IDX_SLOTS) * 8ull + (i % IDX_SLOTS)];
+        if (v && v - 1ull < nbits)
+            atomicOr(bits + ((v - 1ull) >> 5), 1u << ((v - 1ull) & 31u));
+    }
+}
+
+__global__ void keys_to_bits_kernel(const uint64_t *__restrict__ keys, const unsigned long long *__restrict__ n_ptr, uint32_t *__restrict__ bits,
+                                    uint64_t nbits)
+{
+    const uint64_t n = *n_ptr;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint64_t h = keys[i];
+        if (h < nbits)
+            atomicOr(bits + (h >> 5), 1u << (h & 31u));
+    }
+}
+
 int env_int(const char *name, int dflt)
 {
     const char *e = getenv(name);
@@ -179,7 +202,7 @@ static int index_build_locked(brx_set *set, const uint64_t *d_keys, uint64_t n, 
         while (log_lines < 28 && (1ull << log_lines) < n + n / 2)
             log_lines++;
     }
-    while (set->sparse && log_lines < 30 && (7ull << log_lines) < n + n / 4)
+    while (no_bits(set) && log_lines < 30 && (7ull << log_lines) < n + n / 4)
         log_lines++; // a chained table must have room for every key
     if (log_lines < 4 || log_lines > 30) {
         set_error("probe index: log2(lines)=%d out of range 4..30", log_lines);
@@ -211,7 +234,7 @@ static int index_build_locked(brx_set *set, const uint64_t *d_keys, uint64_t n, 
         uint64_t blocks = (n + 255) / 256;
         if (blocks > 256 * 16)
             blocks = 256 * 16;
-        if (set->sparse)
+        if (no_bits(set))
             index_insert_kernel<true><<<(int)blocks, 256, 0, s>>>(d_keys, n, set->d_lines, 32u - (uint32_t)log_lines, (uint32_t)m,
                                                                   (uint32_t)(k - m + 1), k, d_ovf);
         else
@@ -233,7 +256,7 @@ static int index_build_locked(brx_set *set, const uint64_t *d_keys, uint64_t n, 
     set->idx_m = (uint32_t)m;
     set->idx_keys = n;
     set->idx_overflow_keys = ovf;
-    set->idx_exact = set->sparse;
+    set->idx_exact = no_bits(set);
     set->idx_open = false;
     set->idx_valid = true;
     return BRX_OK;
@@ -329,10 +352,39 @@ int index_insert_reads(brx_set *set, const uint8_t *d_bases, const uint64_t *d_o
     return BRX_OK;
 }
 
+int ensure_bits(const brx_set *cset, hipStream_t s, const char *what)
+{
+    brx_set *set = const_cast<brx_set *>(cset);
+    if (set->sparse) {
+        set_error("%s needs the bit vector; a sparse set (k=%d) has none", what, set->k);
+        return BRX_ERR_UNSUPPORTED;
+    }
+    if (!set->bits_stale)
+        return BRX_OK;
+    BRX_TRY(use_device(set->device));
+    std::lock_guard<std::mutex> g(set->idx_mu);
+    if (!set->bits_stale)
+        return BRX_OK;
+    KernelTimer t("bits_materialise", s);
+    BRX_HIP(hipMemsetAsync(set->d_bits, 0, set->nwords * 4, s));
+    if (set->keylist_valid) {
+        keys_to_bits_kernel<<<256 * 8, 256, 0, s>>>(set->d_keylist, set->d_keylist_n, set->d_bits, set->nwords * 32);
+    } else if (set->idx_valid && set->idx_exact) {
+        table_to_bits_kernel<<<256 * 16, 256, 0, s>>>(set->d_lines, 1ull << set->idx_log_lines, set->d_bits, set->nwords * 32);
+    } else {
+        set_error("%s: the set has neither bits, key list nor an exact index", what);
+        return BRX_ERR_ARG;
+    }
+    BRX_HIP(hipGetLastError());
+    BRX_HIP(hipStreamSynchronize(s));
+    set->bits_stale = false;
+    return BRX_OK;
+}
+
 int index_ensure(const brx_set *cset, hipStream_t s)
 {
     brx_set *set = const_cast<brx_set *>(cset);
-    if (!index_wanted(set->k) && !set->sparse)
+    if (!index_wanted(set->k) && !no_bits(set))
         return BRX_OK;
     // several chains may share the set (one per host thread): exactly one of them builds, the others wait
     // here and find the index valid -- a second build would wipe lines the first chain's kernels are reading
@@ -353,12 +405,12 @@ int index_ensure(const brx_set *cset, hipStream_t s)
         BRX_HIP(hipStreamSynchronize(s)); // the bits may still be in flight on `s`; popcount runs on the null stream
         BRX_TRY(brx_set_popcount(set, &n));
     }
-    if (set->sparse && !listed) {
-        set_error("sparse set without a complete key list (%llu solid k-mers counted, room for %llu)", (unsigned long long)n,
+    if (no_bits(set) && !listed) {
+        set_error("set without bit vector and without a complete key list (%llu solid k-mers counted, room for %llu)", (unsigned long long)n,
                   (unsigned long long)set->keylist_cap);
         return BRX_ERR_NOMEM;
     }
-    if (!set->sparse && set->k - index_auto_m(set->k, n) + 1 < 3 && env_int("BRX_INDEX_M", 0) <= 0) {
+    if (!no_bits(set) && set->k - index_auto_m(set->k, n) + 1 < 3 && env_int("BRX_INDEX_M", 0) <= 0) {
         // so many keys that a safe minimizer is (nearly) the k-mer itself: neighbours would not share lines
         set->idx_declined = true;
         return BRX_OK;
@@ -401,7 +453,10 @@ int brx_set_index_build_from_keys_device(brx_set_t *set, const uint64_t *d_keys,
 {
     if (!set || (!d_keys && n))
         return BRX_ERR_ARG;
-    return index_build_from_keys(set, d_keys, n, m, log2_lines, (hipStream_t)stream);
+    int st = index_build_from_keys(set, d_keys, n, m, log2_lines, (hipStream_t)stream);
+    if (st == BRX_OK && no_bits(set) && d_keys != set->d_keylist)
+        set->keylist_valid = false; // without a bit vector the list just given IS the set now (multi-GPU exchange)
+    return st;
 }
 
 int brx_set_keylist_device(const brx_set_t *set, void **d_keys, uint64_t *n, void *stream)
@@ -443,7 +498,7 @@ int brx_set_index_info(const brx_set_t *set, uint64_t *info8)
     for (int i = 0; i < 8; i++)
         info8[i] = 0;
     info8[0] = set->idx_valid ? 1 : 0;
-    info8[6] = index_wanted(set->k) ? 1 : 0;
+    info8[6] = (index_wanted(set->k) || no_bits(set)) ? 1 : 0;
     info8[7] = set->keylist_valid ? 1 : 0;
     if (set->idx_valid) {
         info8[1] = set->idx_m;
@@ -482,7 +537,7 @@ int brx_set_get_batch_indexed(const brx_set_t *set, const uint64_t *forward_kmer
     unsigned long long fb = 0;
     if (e == hipSuccess) {
         IdxView v{set->d_lines, 32u - set->idx_log_lines, set->idx_m, (uint32_t)set->k - set->idx_m + 1u};
-        index_get_kernel<<<(n + 255) / 256, 256>>>(v, set->d_bits, d_k, n, set->k, d_o, d_f);
+        index_get_kernel<<<(n + 255) / 256, 256>>>(v, no_bits(set) ? nullptr : set->d_bits, d_k, n, set->k, d_o, d_f);
         e = hipMemcpy(out, d_o, n, hipMemcpyDeviceToHost);
         if (e == hipSuccess)
             e = hipMemcpy(&fb, d_f, 8, hipMemcpyDeviceToHost);

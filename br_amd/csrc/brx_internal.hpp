@@ -66,6 +66,9 @@ struct brx_set {
     // sparse set (k >= 21: 2^(2k-1) bits do not fit): the solid hashes live in the key list and in the probe
     // index only, whose overflowing lines then chain into the next line instead of falling back to the bits
     bool sparse;
+    // lazy bit vector (k <= 19): a partitioned finish leaves only the key list; the bits are materialised from it
+    // (or from the chained index) by the first entry point that really needs them -- correction with One does not
+    bool bits_stale;
     bool idx_exact;          // the index was built with chaining (answers without the bit vector)
     bool idx_open;           // ... and k-mer by k-mer (brx_set_insert_batch on a sparse set): more can be added
     // probe index over the same set (brx_index.hpp): built on demand, invalidated by every mutation
@@ -93,6 +96,10 @@ int index_insert_reads(brx_set *set, const uint8_t *d_bases, const uint64_t *d_o
                        hipStream_t s);
 // sets of this k have no bit vector
 inline bool sparse_k(int k) { return k >= 21; }
+// the set must be probed through its (chained) index: it has no bit vector, or not right now
+inline bool no_bits(const brx_set *set) { return set->sparse || set->bits_stale; }
+// materialises a stale bit vector (BRX_ERR_UNSUPPORTED for a sparse set)
+int ensure_bits(const brx_set *set, hipStream_t s, const char *what);
 // builds the index from the bitset when the set has none (no-op for k outside the indexed range)
 int index_ensure(const brx_set *set, hipStream_t s);
 inline void index_invalidate(brx_set *set) { set->idx_valid = false; set->idx_declined = false; set->keylist_valid = false; }

@@ -990,6 +990,7 @@ int part_finish_into(brx_counter *c, uint32_t abundance, hipStream_t s, brx_set 
             dst->keylist_valid = true; // the empty list
         } else {
             BRX_HIP(hipMemsetAsync(dst->d_bits, 0, dst->nwords * 4, s));
+            dst->bits_stale = false;
         }
         return BRX_OK;
     } else if (st->batches.size() == 1) {
@@ -1023,9 +1024,13 @@ int part_finish_into(brx_counter *c, uint32_t abundance, hipStream_t s, brx_set 
     // most total / (abundance + 1) of them; real data is far below that, and a list that turns out too short
     // is simply not used (the index is then built from the bit vector)
     const bool emit = dst->sparse || index_wanted(c->k);
+    // lazy bit vector: when the solid hashes are listed anyway, the 2^(2k-4)-byte vector (16 GiB of slices at k = 19)
+    // is written only if somebody asks for it later (ensure_bits); BRX_LAZY_BITS=0 writes it here as before
+    static const bool lazy_on = [] { const char *e = getenv("BRX_LAZY_BITS"); return !(e && *e == '0'); }();
+    const bool lazy = emit && !dst->sparse && lazy_on;
     if (emit) {
-        // (a sparse set has nothing but this list: it gets the exact bound)
-        const uint64_t div = dst->sparse ? abundance + 1u : (abundance + 1u > 8u ? abundance + 1u : 8u);
+        // (a set without bits has nothing but this list: it gets the exact bound)
+        const uint64_t div = (dst->sparse || lazy) ? abundance + 1u : (abundance + 1u > 8u ? abundance + 1u : 8u);
         const uint64_t want = total / div + (1ull << 20);
         if (dst->keylist_cap < want || !dst->d_keylist) {
             if (dst->d_keylist)
@@ -1070,7 +1075,7 @@ int part_finish_into(brx_counter *c, uint32_t abundance, hipStream_t s, brx_set 
         const uint64_t nb = pl.nchild[pl.nlev - 1];
         const uint64_t want_waves = nb < (256ull * 16ull * 8ull) ? nb : (256ull * 16ull * 8ull);
         const int grid = (int)((want_waves + P3_WAVES - 1) / P3_WAVES);
-        if (dst->sparse)
+        if (dst->sparse || lazy)
             final_count_kernel<true, false><<<grid, 64 * P3_WAVES, 0, s>>>(st->d_keys_fin, fin_off, nb, abundance, nullptr,
                                                                           dst->d_keylist, dst->keylist_cap, dst->d_keylist_n);
         else if (emit)
@@ -1083,6 +1088,7 @@ int part_finish_into(brx_counter *c, uint32_t abundance, hipStream_t s, brx_set 
     BRX_HIP(hipGetLastError());
     trace_stage(s, "final count");
     dst->keylist_valid = emit;
+    dst->bits_stale = lazy;
     return BRX_OK;
 }
 

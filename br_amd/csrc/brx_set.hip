@@ -334,14 +334,7 @@ int alloc_set(int k, int device, bool zero, brx_set **out, bool sparse = false)
     return BRX_OK;
 }
 
-int need_bits(const brx_set *set, const char *what)
-{
-    if (set->sparse) {
-        set_error("%s needs the bit vector; a sparse set (k=%d) has none", what, set->k);
-        return BRX_ERR_UNSUPPORTED;
-    }
-    return BRX_OK;
-}
+int need_bits(const brx_set *set, const char *what) { return ensure_bits(set, nullptr, what); }
 
 int grid_for(uint64_t items, int per_block, int cap = 256 * 8)
 {
@@ -469,6 +462,7 @@ int brx_set_insert_batch(brx_set_t *set, const uint8_t *bases, const uint64_t *o
             (void)hipFree(d_o);
         return st;
     }
+    BRX_TRY(need_bits(set, "insert_batch"));
     index_invalidate(set);
     uint8_t *d_b = nullptr;
     uint64_t *d_o = nullptr;
@@ -509,7 +503,7 @@ bool brx_set_get(const brx_set_t *set, uint64_t forward_kmer)
 {
     if (!set || use_device(set->device) != BRX_OK)
         return false;
-    if (set->sparse) {
+    if (no_bits(set)) {
         uint8_t o = 0;
         return brx_set_get_batch(set, &forward_kmer, 1, &o) == BRX_OK && o;
     }
@@ -527,7 +521,7 @@ int brx_set_get_batch(const brx_set_t *set, const uint64_t *forward_kmers, uint3
     BRX_TRY(use_device(set->device));
     if (!n)
         return BRX_OK;
-    if (set->sparse) { // the probe index is all there is
+    if (no_bits(set)) { // the probe index is all there is (right now)
         BRX_TRY(index_ensure(set, nullptr));
         return brx_set_get_batch_indexed(set, forward_kmers, n, out, nullptr);
     }
@@ -580,7 +574,7 @@ int brx_set_popcount(const brx_set_t *set, uint64_t *n_set_bits)
     if (!set || !n_set_bits)
         return BRX_ERR_ARG;
     BRX_TRY(use_device(set->device));
-    if (set->sparse) {
+    if (no_bits(set)) {
         if (set->idx_valid) {
             *n_set_bits = set->idx_keys;
             return BRX_OK;
@@ -617,6 +611,8 @@ int brx_set_device_bits(const brx_set_t *set, void **d_bits, uint64_t *n_bytes)
 }
 
 int brx_set_sparse(const brx_set_t *set) { return set && set->sparse ? 1 : 0; }
+
+int brx_set_bits_state(const brx_set_t *set) { return !set ? -1 : (set->sparse ? 2 : (set->bits_stale ? 1 : 0)); }
 
 void brx_set_free(brx_set_t *set)
 {
@@ -774,7 +770,11 @@ int brx_set_count_finish_into(brx_counter_t *c, uint8_t abundance, void *stream,
     hipStream_t s = (hipStream_t)stream; // nullptr = the legacy default stream, like any HIP API
     if (c->strategy == BRX_COUNT_SORTED)
         return part_finish_into(c, abundance, s, dst);
-    BRX_TRY(need_bits(dst, "the dense count strategy"));
+    if (dst->sparse) {
+        set_error("the dense count strategy needs a bit vector; a sparse set (k=%d) has none", dst->k);
+        return BRX_ERR_UNSUPPORTED;
+    }
+    dst->bits_stale = false; // every word is written below
     {
         KernelTimer t("threshold", s);
         threshold_kernel<<<grid_for(dst->nwords, 256, 256 * 16), 256, 0, s>>>((const uint4 *)c->d_counts, dst->nwords,

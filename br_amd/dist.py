@@ -243,14 +243,14 @@ class GpuPartitionedEngine:
         return buf[:n]
 
     def or_keys(self, keys: torch.Tensor) -> None:
-        if self.solid.is_sparse():
-            return  # no bit vector to OR into: all_keys() rebuilds the probe index from every rank's list
+        if self.solid.bits_state() != 0:
+            return  # no (current) bit vector to OR into: all_keys() rebuilds the probe index from every rank's list
         keys = keys.contiguous()
         self._keep.append(keys)
         self.solid.or_keys_device(keys.data_ptr(), keys.numel(), self.stream)
 
     def all_keys(self, lists) -> None:
-        if self.solid.index_info()["wanted"] or self.solid.is_sparse():
+        if self.solid.index_info()["wanted"] or self.solid.bits_state() != 0:
             keys = torch.cat(lists) if len(lists) > 1 else lists[0]
             self._keep.append(keys)
             self.solid.index_build_from_keys_device(keys.data_ptr(), keys.numel(), 0, 0, self.stream)

@@ -147,6 +147,10 @@ class Pcon(KmerSet):
         """k >= 21: no bit vector, the solid k-mers live in the key list / probe index only (include/brx.h)"""
         return bool(_lib.lib().brx_set_sparse(self._h))
 
+    def bits_state(self) -> int:
+        """0 bit vector current, 1 lazy (materialised on demand), 2 sparse (include/brx.h brx_set_bits_state)"""
+        return int(_lib.lib().brx_set_bits_state(self._h))
+
     def popcount(self) -> int:
         n = C.c_uint64(0)
         _lib.check(_lib.lib().brx_set_popcount(self._h, C.byref(n)))

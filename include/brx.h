@@ -102,6 +102,12 @@ int brx_set_popcount(const brx_set_t *set, uint64_t *n_set_bits);
  * entries that need the bit vector (.solid import/export, set, insert_batch, device_bits, extract/or_keys)
  * return BRX_ERR_UNSUPPORTED.  Sets are built by the partitioned counter (k <= 21).                          */
 int brx_set_sparse(const brx_set_t *set);
+/* 0: the bit vector is in HBM and current; 1: LAZY -- a partitioned brx_set_count_finish[_into] listed the solid
+ * hashes and left the 2^(2k-4)-byte vector unwritten (16 GiB at k = 19); it is materialised by the first entry
+ * that needs it (export, device_bits, set, insert_batch, extract/or_keys, correction with a walking method);
+ * get / get_batch / popcount / correction with One answer from the key list / probe index (BRX_LAZY_BITS=0
+ * writes the vector at finish time as the reference does); 2: sparse set, no bit vector ever.                */
+int brx_set_bits_state(const brx_set_t *set);
 /* device view of the packed bit array (for RCCL all-gather / OR across ranks)              */
 int brx_set_device_bits(const brx_set_t *set, void **d_bits, uint64_t *n_bytes);
 /* sparse replication of the set: list the set bits of [first_hash, first_hash+n_hashes) (both

@@ -131,3 +131,36 @@ def test_index_off_switch(raw_reads, monkeypatch):
     gs = br_amd.Pcon.from_count(raw_reads[:50], 15, 1)
     br_amd.Chain(gs, [("one", 5, 7)], two_side=True).correct_reads(raw_reads[:5])
     assert not gs.index_info()["valid"]
+
+
+def test_lazy_bit_vector(raw_reads, monkeypatch):
+    """a partitioned finish lists the solid hashes and leaves the bit vector unwritten (bits_state 1): membership,
+    popcount and One answer from the chained index -- also for keys that overflowed their line -- and the vector
+    appears, identical to the oracle's, when something asks for it"""
+    k, a = 15, 1
+    reads = raw_reads[:150]
+    ref = O.Solid.from_count(k, O.count_reads(k, reads), a)
+    cnt = br_amd.Counter(k, 0)
+    cnt.add_reads(reads)
+    gs = cnt.finish(a)
+    assert gs.bits_state() == 1
+    assert gs.popcount() == ref.popcount()
+    monkeypatch.setenv("BRX_INDEX_LOG_LINES", "12")  # far too few lines: the build takes the smallest table that fits
+    sk = _solid_kmers(ref, k)
+    q = _queries(sk, k, np.random.default_rng(7))
+    want = np.array([ref.get(int(x)) for x in q])
+    assert np.array_equal(gs.get_many(q), want)  # builds the chained index from the key list
+    info = gs.index_info()
+    assert info["valid"] and info["overflow_keys"] > info["keys"] // 10
+    assert gs.bits_state() == 1
+    om = O.build_methods(ref, ["one"], 5, 7)
+    got = br_amd.Chain(gs, [("one", 5, 7)], two_side=False).correct_reads(reads)
+    assert gs.bits_state() == 1  # One never needed the vector
+    for r, g in zip(reads, got):
+        assert g == O.correct_record(om, r, False)
+    om = O.build_methods(ref, ["graph"], 5, 7)
+    got = br_amd.Chain(gs, [("graph", 5, 7)], two_side=False).correct_reads(reads[:40])
+    assert gs.bits_state() == 0  # a walking method materialised it
+    for r, g in zip(reads[:40], got):
+        assert g == O.correct_record(om, r, False)
+    assert gs.to_solid_bytes() == ref.to_bytes()
