@@ -491,6 +491,17 @@ __global__ __launch_bounds__(64 * P3_WAVES) void final_count_kernel(const uint16
         cnt[w] = 0;
     for (uint32_t w = lane; w < BIT_WORDS; w += 64)
         bmp[w] = 0;
+    // appends `hkey` of every lane whose flag is set (called by the whole wave)
+    auto emit_if = [&](bool flag, uint64_t hkey) {
+        const uint64_t bal = __ballot(flag);
+        if (bal) {
+            if (ecount + 64u > EMIT_CAP)
+                emit_flush();
+            if (flag)
+                ebuf[ecount + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u))] = hkey;
+            ecount += (uint32_t)__builtin_popcountll(bal);
+        }
+    };
     asm volatile("" ::: "memory");
 
     // consecutive buckets go to one wave, so its key stream is contiguous
@@ -544,17 +555,21 @@ __global__ __launch_bounds__(64 * P3_WAVES) void final_count_kernel(const uint16
                 const bool act = (uint64_t)lane < n;
                 const uint32_t key = act ? stage[(uint32_t)(s - base4) + lane] : 0u;
                 const uint32_t word = key & (CNT_WORDS - 1u), half = key >> (F_BITS - 1);
-                bool hot = false;
+                bool hot = false, cross = false;
                 if (act) {
                     // the lane that increments a counter last sees its final value minus one, so
                     // "old + 1 > abundance" on every lane sets exactly the bits of the final counts
                     const uint32_t old = (atomicAdd(&cnt[word], 1u << (16u * half)) >> (16u * half)) & 0xffffu;
                     const uint32_t c = old + 1u;
                     hot = (c > 255u ? 255u : c) > abundance; // pcon's u8 counters saturate at 255
-                    if (hot)
+                    cross = old == abundance && abundance < 255u; // exactly one lane per solid hash sees the crossing
+                    if (BITS && hot)
                         atomicOr(&bmp[key >> 5], 1u << (key & 31u));
                 }
-                any_bit = __ballot(hot) != 0ull;
+                if (BITS)
+                    any_bit = __ballot(hot) != 0ull;
+                else if (EMIT)
+                    emit_if(cross, (g0 + (uint64_t)j) * F_SIZE + (uint64_t)key); // no slice: list the hash right away
                 asm volatile("" ::: "memory");
                 if (act)
                     cnt[word] = 0;
@@ -579,20 +594,27 @@ __global__ __launch_bounds__(64 * P3_WAVES) void final_count_kernel(const uint16
                         asm volatile("" ::: "memory");
                     }
                 }
-                for (uint32_t w = lane; w < CNT_WORDS; w += 64) {
+                for (uint32_t w = lane; w < CNT_WORDS; w += 64) { // (wave-uniform trip count)
                     const uint32_t v = cnt[w];
-                    if (v) {
-                        // word w holds hashes w (low half) and w + 2048 (high half)
-                        const uint32_t c0 = v & 0xffffu, c1 = v >> 16;
-                        if ((c0 > 255u ? 255u : c0) > abundance)
+                    // word w holds hashes w (low half) and w + 2048 (high half)
+                    const uint32_t c0 = v & 0xffffu, c1 = v >> 16;
+                    const bool s0 = (c0 > 255u ? 255u : c0) > abundance, s1 = (c1 > 255u ? 255u : c1) > abundance;
+                    if (BITS) {
+                        if (s0)
                             atomicOr(&bmp[w >> 5], 1u << (w & 31u));
-                        if ((c1 > 255u ? 255u : c1) > abundance)
+                        if (s1)
                             atomicOr(&bmp[(w + CNT_WORDS) >> 5], 1u << (w & 31u));
-                        cnt[w] = 0;
+                    } else if (EMIT) {
+                        emit_if(s0, (g0 + (uint64_t)j) * F_SIZE + (uint64_t)w);
+                        emit_if(s1, (g0 + (uint64_t)j) * F_SIZE + (uint64_t)(w + CNT_WORDS));
                     }
+                    if (v)
+                        cnt[w] = 0;
                 }
             }
             asm volatile("" ::: "memory");
+            if (!BITS)
+                continue; // hashes were listed above, there is no slice to write
             // flush the slice: 128 words = 2 per lane (LDS is only touched when a bit was set)
             uint32_t *dst = bits + (g0 + (uint64_t)j) * BIT_WORDS;
             uint32_t w0 = 0, w1 = 0;
@@ -602,8 +624,7 @@ __global__ __launch_bounds__(64 * P3_WAVES) void final_count_kernel(const uint16
                 bmp[2 * lane] = 0;
                 bmp[2 * lane + 1] = 0;
             }
-            if (BITS)
-                *reinterpret_cast<uint2 *>(dst + 2 * lane) = make_uint2(w0, w1);
+            *reinterpret_cast<uint2 *>(dst + 2 * lane) = make_uint2(w0, w1);
             asm volatile("" ::: "memory");
             if (EMIT && any_bit) {
                 // one hash per lane and turn (slices hold a handful of bits: usually a single turn)
