@@ -526,7 +526,7 @@ __global__ __launch_bounds__(256, (M == BRX_ONE ? 6 : 1)) void correct_kernel(Pa
                 // known to be non-solid -> three probes instead of four
                 do_probe = gl < 4 && ((p.flags & 2u) || (uint64_t)gl != (kmer & 3ull));
                 pk = add_nuc(kmer >> 2, (uint64_t)gl, mask);
-                if ((HAS_ONE || HAS_TWO) && !(p.flags & 8u)) {
+                if ((HAS_ONE || HAS_TWO || HAS_GREEDY) && !(p.flags & 8u)) {
                     // the bases the scenarios will look at, fetched once (one coalesced load per group)
                     const uint32_t wp = i + (uint32_t)gl;
                     win = group_window((gl < WB && wp < n) ? nuc2bit(ld(wp)) : 0ull);
@@ -594,8 +594,13 @@ __global__ __launch_bounds__(256, (M == BRX_ONE ? 6 : 1)) void correct_kernel(Pa
                 if (sc_active) {
                     uint32_t off;
                     pk = two_apply(tw, (int)sc_s, mask, off);
-                    for (uint32_t q = 0; q <= j; q++) // get_score look-ahead, exist/mod.rs:33-41
-                        pk = add_nuc(pk, nuc2bit(ld(i + off + q)), mask);
+                    // get_score look-ahead, exist/mod.rs:33-41: seq[i+off .. i+off+j], out of the window fetched at ALTS
+                    if (off + j + 1u <= (uint32_t)WB && !(p.flags & 8u)) {
+                        pk = ext(pk, win, off, j + 1u);
+                    } else {
+                        for (uint32_t q = 0; q <= j; q++)
+                            pk = add_nuc(pk, nuc2bit(ld(i + off + q)), mask);
+                    }
                     do_probe = true;
                 }
             } else if (HAS_TWO && st == ST_TMORE) {
@@ -607,8 +612,12 @@ __global__ __launch_bounds__(256, (M == BRX_ONE ? 6 : 1)) void correct_kernel(Pa
                         pk = corr >> 2;
                         for (uint32_t q = 0; q < nc; q++)
                             pk = add_nuc(pk, (uint64_t)((cb >> (2 * (nc - 1 - q))) & 3u), mask);
-                        for (uint32_t q = 0; q <= c; q++)
-                            pk = add_nuc(pk, nuc2bit(ld(i + offc + q)), mask);
+                        if (offc + c + 1u <= (uint32_t)WB && !(p.flags & 8u)) {
+                            pk = ext(pk, win, offc, c + 1u);
+                        } else {
+                            for (uint32_t q = 0; q <= c; q++)
+                                pk = add_nuc(pk, nuc2bit(ld(i + offc + q)), mask);
+                        }
                         do_probe = true;
                     }
                 }
@@ -620,9 +629,13 @@ __global__ __launch_bounds__(256, (M == BRX_ONE ? 6 : 1)) void correct_kernel(Pa
                 const uint32_t rem2 = n - i - git;
                 const uint32_t e = sub * G + (uint32_t)gl;
                 if (rem2 >= c && e < c) {
-                    pk = wk;
-                    for (uint32_t q = 0; q <= e; q++)
-                        pk = add_nuc(pk, nuc2bit(ld(i + git + q)), mask);
+                    if (git + e + 1u <= (uint32_t)WB && !(p.flags & 8u)) {
+                        pk = ext(wk, win, git, e + 1u);
+                    } else {
+                        pk = wk;
+                        for (uint32_t q = 0; q <= e; q++)
+                            pk = add_nuc(pk, nuc2bit(ld(i + git + q)), mask);
+                    }
                     do_probe = true;
                 }
             }
