@@ -4,7 +4,9 @@
 
 namespace {
 
-constexpr int SCAN_ITEMS = 1024; // reads per 256-thread block (4 per thread)
+constexpr int SCAN_IPT = 16;                // items per thread
+constexpr int SCAN_ITEMS = 256 * SCAN_IPT;  // items per 256-thread block (the single-block scan of the block sums is
+                                            // serial in the number of blocks: 4096 items keep it at a few dozen rounds)
 
 __global__ __launch_bounds__(256) void lens_block_sum_kernel(const uint32_t *__restrict__ lens, uint32_t n,
                                                              uint64_t *__restrict__ block_sums)
@@ -62,11 +64,11 @@ __global__ __launch_bounds__(256) void lens_scan_kernel(const uint32_t *__restri
                                                         uint64_t *__restrict__ out_offsets)
 {
     __shared__ unsigned long long sh[256];
-    const uint32_t base = blockIdx.x * SCAN_ITEMS + threadIdx.x * 4;
-    uint32_t v[4];
+    const uint32_t base = blockIdx.x * SCAN_ITEMS + threadIdx.x * SCAN_IPT;
+    uint32_t v[SCAN_IPT];
     unsigned long long mine = 0;
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
+    for (int q = 0; q < SCAN_IPT; q++) {
         v[q] = (base + q < n) ? lens[base + q] : 0u;
         mine += v[q];
     }
@@ -80,7 +82,7 @@ __global__ __launch_bounds__(256) void lens_scan_kernel(const uint32_t *__restri
     }
     unsigned long long run = block_sums[blockIdx.x] + sh[threadIdx.x] - mine;
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
+    for (int q = 0; q < SCAN_IPT; q++) {
         if (base + q <= n) // index n receives the grand total
             out_offsets[base + q] = run;
         run += v[q];
