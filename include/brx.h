@@ -23,6 +23,10 @@
  *     transfers themselves.
  *   - a brx_set_t is immutable once built/loaded and may be shared by any number of
  *     chains; a brx_chain_t owns its workspace and serialises concurrent calls.
+ *   - what a set IS is the reference's: the canonical k-mers with `KmerSet::get` = true.
+ *     How it is HELD in HBM varies (bit vector for k <= 19, possibly lazy; key list +
+ *     probe index; sparse table for k >= 21) and never changes an answer -- see
+ *     brx_set_bits_state / brx_set_sparse / brx_set_index_* below and DESIGN.md 3, 5.
  *   - there is NO CPU fallback: without a usable gfx950 device every compute entry
  *     returns BRX_ERR_NODEVICE.
  */
@@ -143,9 +147,10 @@ void brx_set_free(brx_set_t *set);
 
 /* ---- set build by counting: src/main.rs:72-115 -------------------------------------------
  * Counter::<u8>::new(k) -> count_fasta -> Solid::from_count(k, counts, abundance).
- * k must be odd (Fasta::kmer_size forces it, src/cli.rs:277-279) and <= 31.
- * strategy: BRX_COUNT_DENSE keeps the reference's 2^(2k-1)-byte u8 table in HBM;
- * BRX_COUNT_SORTED keeps the canonical hashes and sorts them (same bitset, no table).     */
+ * k must be odd (Fasta::kmer_size forces it, src/cli.rs:277-279).
+ * strategy: BRX_COUNT_DENSE keeps the reference's 2^(2k-1)-byte u8 table in HBM (k <= 19: 128 GiB);
+ * BRX_COUNT_SORTED radix-partitions the canonical hashes and counts them bucket by bucket (same
+ * set, no table; k <= 21); BRX_COUNT_AUTO = SORTED for 15 <= k <= 21, else DENSE.                 */
 enum { BRX_COUNT_AUTO = 0, BRX_COUNT_DENSE = 1, BRX_COUNT_SORTED = 2 };
 int brx_set_count_begin(uint8_t k, int device, int strategy, brx_counter_t **out);
 int brx_set_count_add_batch(brx_counter_t *c, const uint8_t *bases, const uint64_t *offsets, uint32_t n_reads);
