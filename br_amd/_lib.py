@@ -91,6 +91,8 @@ SIGNATURES = {
     "brx_buf_free": (None, [_vp]),
     "brx_run_correction_fd": (C.c_int, [_vp, C.POINTER(Method), C.c_uint32, C.c_bool, C.c_int, C.c_int, C.c_uint32, _u64p]),
     "brx_count_fasta_fd": (C.c_int, [_vp, C.c_int, C.c_uint32, _u64p]),
+    "brx_set_insert_fasta_fd": (C.c_int, [_vp, C.c_int, C.c_uint32, _u64p]),
+    "brx_set_insert_batch_device": (C.c_int, [_vp, _vp, _vp, C.c_uint32, C.c_uint64, _vp]),
     "brx_synth_genome_device": (C.c_int, [C.POINTER(Synth), C.c_int, _vp, _vp]),
     "brx_synth_reads_device": (C.c_int, [C.POINTER(Synth), C.c_int, _vp, C.c_uint64, C.c_uint32, _vp, C.c_uint64,
                                          _vp, _u64p, _vp]),

@@ -139,7 +139,8 @@ def build_set(args) -> Pcon:
                 return Pcon.from_pcon_solid(f.read(), dev)
         if args.kmer_size is None:
             raise SystemExit("Error: Solid input fasta require kmer size")            # error.rs SolidRequireKmerSize
-        return Pcon.from_fasta(_records([args.sub_input]), args.kmer_size, dev)
+        with open_input(args.sub_input) as f:
+            return Pcon.from_fasta_file(f, args.kmer_size, dev)
     if args.subcommand == "count":
         raise SystemExit("the pcon count-file format is not implemented on the HIP path (unpinned, SURVEY 8(f) N3)")
     # large-kmer -f fasta: set::Hash::from_fasta (src/set/hash.rs:40-60, src/main.rs:147-163) = every canonical k-mer of
@@ -148,7 +149,8 @@ def build_set(args) -> Pcon:
     # of the {k-mer, revcomp} pair for even k.
     if args.kmer_size % 2 == 0 or not 1 <= args.kmer_size <= 31:
         raise SystemExit("Error: large-kmer mode needs an odd k <= 31 on the HIP path (k=%d)" % args.kmer_size)
-    return Pcon.from_fasta(_records([args.sub_input]), args.kmer_size, dev)
+    with open_input(args.sub_input) as f:
+        return Pcon.from_fasta_file(f, args.kmer_size, dev)
 
 
 def main(argv: Optional[List[str]] = None) -> int:

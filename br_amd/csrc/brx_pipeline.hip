@@ -434,6 +434,92 @@ void format_batch(const Batch &b, std::vector<char> &o)
     o.resize((size_t)(w - o.data()));
 }
 
+// shared by brx_count_fasta_fd / brx_set_insert_fasta_fd: parse on a thread, hand every batch (already on the
+// device) to `consume(d_bases, d_offsets, n_reads, total_bases, stream)`
+template <class F>
+int stream_fasta_batches(int device, int in_fd, uint32_t max_batch_records, hipStream_t s, uint64_t *stats8, F consume)
+{
+    const double t_start = now_s();
+    std::vector<Batch> slots(3);
+    Queue<Batch *> q_free, q_ready;
+    Shared sh;
+    double t_read = 0, t_gpu = 0;
+    uint64_t n_records = 0, bases_in = 0, n_batches = 0;
+    for (auto &sl : slots)
+        q_free.push(&sl);
+    std::thread reader([&] {
+        if (hipSetDevice(device) != hipSuccess) {
+            set_error("hipSetDevice in reader thread failed");
+            sh.fail(BRX_ERR_HIP);
+            q_ready.close();
+            return;
+        }
+        FastaBatcher fb(in_fd, max_batch_records);
+        for (;;) {
+            Batch *b = nullptr;
+            if (!q_free.pop(b) || sh.failed())
+                break;
+            const double t0 = now_s();
+            int st = fb.fill(*b);
+            t_read += now_s() - t0;
+            if (st != BRX_OK) {
+                sh.fail(st);
+                break;
+            }
+            const bool last = b->last;
+            q_ready.push(b);
+            if (last)
+                break;
+        }
+        q_ready.close();
+    });
+    DevBufs dv;
+    Batch *b = nullptr;
+    while (q_ready.pop(b)) {
+        if (!sh.failed() && b->n()) {
+            const double t0 = now_s();
+            int st = dv.ensure(b->total, b->n());
+            hipError_t e = hipSuccess;
+            if (st == BRX_OK && b->total)
+                e = hipMemcpyAsync(dv.d_in, b->bases.p, b->total, hipMemcpyHostToDevice, s);
+            if (st == BRX_OK && e == hipSuccess)
+                e = hipMemcpyAsync(dv.d_off, b->offsets.data(), ((size_t)b->n() + 1) * 8, hipMemcpyHostToDevice, s);
+            if (st == BRX_OK && e == hipSuccess)
+                st = consume(dv.d_in, dv.d_off, b->n(), b->total, s);
+            if (st == BRX_OK && e == hipSuccess)
+                e = hipStreamSynchronize(s); // the batch's device buffers are reused by the next one
+            if (e != hipSuccess) {
+                set_error("fasta stream: %s", hipGetErrorString(e));
+                st = BRX_ERR_HIP;
+            }
+            t_gpu += now_s() - t0;
+            if (st != BRX_OK)
+                sh.fail(st);
+            n_records += b->n();
+            bases_in += b->total;
+            n_batches++;
+        }
+        q_free.push(b);
+    }
+    reader.join();
+    q_free.close();
+    if (stats8) {
+        for (int i = 0; i < 8; i++)
+            stats8[i] = 0;
+        stats8[0] = n_records;
+        stats8[1] = bases_in;
+        stats8[3] = n_batches;
+        stats8[4] = (uint64_t)(t_read * 1e9);
+        stats8[5] = (uint64_t)(t_gpu * 1e9);
+        stats8[7] = (uint64_t)((now_s() - t_start) * 1e9);
+    }
+    if (sh.status != BRX_OK) {
+        set_error("%s", sh.message.c_str());
+        return sh.status;
+    }
+    return BRX_OK;
+}
+
 } // namespace
 
 extern "C" {
@@ -593,6 +679,23 @@ int brx_run_correction_fd(const brx_set_t *set, const brx_method_t *methods, uin
     return BRX_OK;
 }
 
+int brx_set_insert_fasta_fd(brx_set_t *set, int in_fd, uint32_t max_batch_records, uint64_t *stats8)
+{
+    if (!set) {
+        set_error("null set");
+        return BRX_ERR_ARG;
+    }
+    BRX_TRY(use_device(set->device));
+    hipStream_t s = nullptr;
+    BRX_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    int st = stream_fasta_batches(set->device, in_fd, max_batch_records, s, stats8,
+                                  [&](const uint8_t *d_b, const uint64_t *d_o, uint32_t n, uint64_t total, hipStream_t st_) {
+                                      return brx_set_insert_batch_device(set, d_b, d_o, n, total, st_);
+                                  });
+    (void)hipStreamDestroy(s);
+    return st;
+}
+
 int brx_count_fasta_fd(brx_counter_t *c, int in_fd, uint32_t max_batch_records, uint64_t *stats8)
 {
     if (!c) {
@@ -600,87 +703,10 @@ int brx_count_fasta_fd(brx_counter_t *c, int in_fd, uint32_t max_batch_records, 
         return BRX_ERR_ARG;
     }
     BRX_TRY(use_device(c->device));
-    const int device = c->device;
-    const double t_start = now_s();
-    std::vector<Batch> slots(3);
-    Queue<Batch *> q_free, q_ready;
-    Shared sh;
-    double t_read = 0, t_gpu = 0;
-    uint64_t n_records = 0, bases_in = 0, n_batches = 0;
-    for (auto &s : slots)
-        q_free.push(&s);
-    std::thread reader([&] {
-        if (hipSetDevice(device) != hipSuccess) {
-            set_error("hipSetDevice in reader thread failed");
-            sh.fail(BRX_ERR_HIP);
-            q_ready.close();
-            return;
-        }
-        FastaBatcher fb(in_fd, max_batch_records);
-        for (;;) {
-            Batch *b = nullptr;
-            if (!q_free.pop(b) || sh.failed())
-                break;
-            const double t0 = now_s();
-            int st = fb.fill(*b);
-            t_read += now_s() - t0;
-            if (st != BRX_OK) {
-                sh.fail(st);
-                break;
-            }
-            const bool last = b->last;
-            q_ready.push(b);
-            if (last)
-                break;
-        }
-        q_ready.close();
-    });
-    DevBufs dv;
-    hipStream_t s = c->stream;
-    Batch *b = nullptr;
-    while (q_ready.pop(b)) {
-        if (!sh.failed() && b->n()) {
-            const double t0 = now_s();
-            int st = dv.ensure(b->total, b->n());
-            hipError_t e = hipSuccess;
-            if (st == BRX_OK && b->total)
-                e = hipMemcpyAsync(dv.d_in, b->bases.p, b->total, hipMemcpyHostToDevice, s);
-            if (st == BRX_OK && e == hipSuccess)
-                e = hipMemcpyAsync(dv.d_off, b->offsets.data(), ((size_t)b->n() + 1) * 8, hipMemcpyHostToDevice, s);
-            if (st == BRX_OK && e == hipSuccess)
-                st = brx_set_count_add_batch_device(c, dv.d_in, dv.d_off, b->n(), b->total, s);
-            if (st == BRX_OK && e == hipSuccess)
-                e = hipStreamSynchronize(s); // the batch's device buffers are reused by the next one
-            if (e != hipSuccess) {
-                set_error("count_fasta: %s", hipGetErrorString(e));
-                st = BRX_ERR_HIP;
-            }
-            t_gpu += now_s() - t0;
-            if (st != BRX_OK)
-                sh.fail(st);
-            n_records += b->n();
-            bases_in += b->total;
-            n_batches++;
-        }
-        q_free.push(b);
-    }
-    reader.join();
-    q_free.close();
-    if (stats8) {
-        for (int i = 0; i < 8; i++)
-            stats8[i] = 0;
-        stats8[0] = n_records;
-        stats8[1] = bases_in;
-        stats8[3] = n_batches;
-        stats8[4] = (uint64_t)(t_read * 1e9);
-        stats8[5] = (uint64_t)(t_gpu * 1e9);
-        stats8[7] = (uint64_t)((now_s() - t_start) * 1e9);
-    }
-    if (sh.status != BRX_OK) {
-        set_error("%s", sh.message.c_str());
-        return sh.status;
-    }
-    return BRX_OK;
+    return stream_fasta_batches(c->device, in_fd, max_batch_records, c->stream, stats8,
+                                [&](const uint8_t *d_b, const uint64_t *d_o, uint32_t n, uint64_t total, hipStream_t st_) {
+                                    return brx_set_count_add_batch_device(c, d_b, d_o, n, total, st_);
+                                });
 }
 
 } // extern "C"

@@ -486,6 +486,30 @@ int brx_set_insert_batch(brx_set_t *set, const uint8_t *bases, const uint64_t *o
     return BRX_OK;
 }
 
+int brx_set_insert_batch_device(brx_set_t *set, const uint8_t *d_bases, const uint64_t *d_offsets, uint32_t n_reads,
+                                uint64_t total_bases, void *stream)
+{
+    if (!set || !d_offsets || (!d_bases && total_bases)) {
+        set_error("null argument");
+        return BRX_ERR_ARG;
+    }
+    BRX_TRY(check_k(set->k, true));
+    BRX_TRY(use_device(set->device));
+    if (n_reads == 0)
+        return BRX_OK;
+    hipStream_t s = (hipStream_t)stream;
+    if (set->sparse)
+        return index_insert_reads(set, d_bases, d_offsets, n_reads, total_bases, s);
+    BRX_TRY(ensure_bits(set, s, "insert_batch"));
+    index_invalidate(set);
+    {
+        KernelTimer t("insert", s);
+        kmer_scatter_kernel<1><<<grid_for(n_reads, 1, 1 << 20), 256, 0, s>>>(d_bases, d_offsets, n_reads, set->k, set->d_bits);
+    }
+    BRX_HIP(hipGetLastError());
+    return BRX_OK;
+}
+
 int brx_set_set(brx_set_t *set, uint64_t forward_kmer, bool value)
 {
     if (!set)

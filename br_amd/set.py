@@ -90,6 +90,16 @@ class Pcon(KmerSet):
         return s
 
     @classmethod
+    def from_fasta_file(cls, f, k: int, device: int = 0) -> "Pcon":
+        """from_fasta over a FASTA stream (binary file object) through the native host pipeline"""
+        from . import hostio
+        s = cls.new(k, device)
+        st = (C.c_uint64 * 8)()
+        with hostio.input_fd(f) as fd:
+            _lib.check(_lib.lib().brx_set_insert_fasta_fd(s._h, fd, 0, st))
+        return s
+
+    @classmethod
     def from_count(cls, reads: Iterable[bytes], k: int, abundance: int, device: int = 0, batch: int = 8192,
                    strategy: int = _lib.COUNT_AUTO) -> "Pcon":
         """`br fasta -k K -a A` (src/main.rs:72-115): count canonical k-mers (u8, saturating),

@@ -88,6 +88,9 @@ int brx_set_new_from_solid_bytes(const uint8_t *buf, size_t len, int device, brx
 /* Pcon::from_fasta (presence only): OR in every canonical k-mer of every read of length >= k
  *                                                                  src/set/pcon.rs:47-112  */
 int brx_set_insert_batch(brx_set_t *set, const uint8_t *bases, const uint64_t *offsets, uint32_t n_reads);
+/* same on device buffers, asynchronous on `stream` for bit-vector sets                          */
+int brx_set_insert_batch_device(brx_set_t *set, const uint8_t *d_bases, const uint64_t *d_offsets, uint32_t n_reads,
+                                uint64_t total_bases, void *stream);
 /* Solid::set(kmer, value) -- host-side slow path (tests, csv input) src/set/pcon.rs:38      */
 int brx_set_set(brx_set_t *set, uint64_t forward_kmer, bool value);
 /* KmerSet::get                                                     src/set/pcon.rs:189-191 */
@@ -216,6 +219,9 @@ int brx_run_correction_fd(const brx_set_t *set, const brx_method_t *methods, uin
                           int out_fd, uint32_t max_batch_records, uint64_t *stats8);
 /* Counter::count_fasta(reader, record_buffer) (src/main.rs:73-78): counts every record of the FASTA stream */
 int brx_count_fasta_fd(brx_counter_t *c, int in_fd, uint32_t max_batch_records, uint64_t *stats8);
+/* Pcon::from_fasta / Hash::from_fasta (src/set/pcon.rs:47-112, src/set/hash.rs:40-60): every record of the stream
+ * inserted presence-only (`br solid -f fasta`, `br large-kmer -f fasta`)                                          */
+int brx_set_insert_fasta_fd(brx_set_t *set, int in_fd, uint32_t max_batch_records, uint64_t *stats8);
 
 /* ---- synthetic reads: deterministic, identical on host and device ----------
  * genome: i.i.d. uniform ACGT of length genome_len (seed); read r: window of read_len

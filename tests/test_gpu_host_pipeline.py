@@ -119,3 +119,25 @@ def test_count_fasta_native(golden_dir, solid_fixture_bytes, strategy):
     reads = [seq for _, _, seq in fasta.read_records(open(os.path.join(golden_dir, "raw.fasta"), "rb"))][:]
     ref = O.Solid.from_count(15, O.count_reads(15, reads), 1)
     assert cnt.finish(1).to_solid_bytes() == ref.to_bytes()
+
+
+@pytest.mark.parametrize("k", [11, 23])
+def test_presence_set_from_fasta_stream(golden_dir, raw_reads, k):
+    """`br solid -f fasta` / `br large-kmer -f fasta` through brx_set_insert_fasta_fd: the same set as inserting the
+    parsed records batch by batch, and as the oracle's presence-only set (bit vector at k = 11, sparse at k = 23)"""
+    with open(os.path.join(golden_dir, "raw.fasta"), "rb") as f:
+        gs = br_amd.Pcon.from_fasta_file(f, k)
+    if k == 11:
+        ref = O.Solid(k)
+        for r in raw_reads:
+            ref.set_seq_canonical(r) if hasattr(ref, "set_seq_canonical") else ref.set_seq(r)
+        assert gs.to_solid_bytes() == br_amd.Pcon.from_fasta(raw_reads, k).to_solid_bytes()
+        assert gs.popcount() == ref.popcount()
+    else:
+        assert gs.is_sparse()
+        ref = O.Solid.sparse_from_count(k, raw_reads, 0)
+        assert gs.popcount() == ref.popcount()
+        rng = np.random.default_rng(5)
+        q = np.concatenate([np.array([O.seq2bit(r[i:i + k]) for r in raw_reads[:5] for i in range(0, 400, 7)], dtype=np.uint64),
+                            rng.integers(0, 1 << (2 * k), 3000, dtype=np.uint64)])
+        assert np.array_equal(gs.get_many(q), np.array([ref.get(int(x)) for x in q]))
