@@ -315,6 +315,26 @@ __device__ bool greedy_align(const GreedyLds &L, int gl, int m, int n, int nb, i
 }
 
 // look-ahead k-mers per scenario probed in the SCEN round that starts at look-ahead index `sub`
+// index of the n-th (0-based) set bit of a small mask
+__device__ __forceinline__ uint32_t nth_bit(uint32_t mask, uint32_t n)
+{
+    for (uint32_t q = 0; q < n; q++)
+        mask &= mask - 1u;
+    return (uint32_t)__ffs(mask) - 1u;
+}
+
+// look-aheads per surviving scenario in a TSCORE round (Two): one while every valid scenario is still in, then as
+// many as the group's lanes allow
+__device__ __forceinline__ uint32_t two_width(uint32_t sub, uint32_t c, int G, uint32_t alive)
+{
+    const uint32_t left = c - sub;
+    const uint32_t na = (uint32_t)__popc(alive);
+    uint32_t cap = sub == 0u ? 1u : (uint32_t)G / (na ? na : 1u);
+    if (cap < 1u)
+        cap = 1u;
+    return left < cap ? left : cap;
+}
+
 // (the lanes are dealt to the scenarios still alive, so once the wrong ones have died the survivor's
 // remaining look-aheads fit one round even in an 8-lane group)
 __device__ __forceinline__ uint32_t scen_width(uint32_t sub, uint32_t c, int G, uint32_t flags, uint32_t failmask)
@@ -586,11 +606,14 @@ __global__ __launch_bounds__(256, (M == BRX_ONE ? 6 : 1)) void correct_kernel(Pa
                     do_probe = ok;
                 }
             } else if (HAS_TWO && st == ST_TSCORE) {
-                const uint32_t e = sub * G + (uint32_t)gl;
-                sc_active = e < (uint32_t)T_N * c;
-                sc_s = sc_active ? e / c : 0u;
-                const uint32_t j = sc_active ? e % c : 0u;
-                sc_active = sc_active && ((tvalid >> sc_s) & 1u) && !((failmask >> sc_s) & 1u);
+                // get_score of the scenarios still alive, `sub` look-aheads done so far: first the nearest k-mer of
+                // every valid scenario (13 lanes; most scenarios die there), then the lanes are dealt to the survivors
+                const uint32_t alive = tvalid & ~failmask;
+                const uint32_t width = two_width(sub, c, G, alive);
+                const uint32_t ord = (uint32_t)gl / width;
+                sc_active = ord < (uint32_t)__popc(alive);
+                sc_s = sc_active ? nth_bit(alive, ord) : 0u;
+                const uint32_t j = sub + (uint32_t)gl % width;
                 if (sc_active) {
                     uint32_t off;
                     pk = two_apply(tw, (int)sc_s, mask, off);
@@ -948,22 +971,18 @@ __global__ __launch_bounds__(256, (M == BRX_ONE ? 6 : 1)) void correct_kernel(Pa
             } else if (HAS_TWO && st == ST_TSCORE) {
                 const bool bad = sc_active && !sol;
                 const uint64_t badmask = (__ballot(bad) >> gshift) & GM;
-                const uint32_t e0 = sub * G;
-                const uint32_t sc_first = e0 / c;
-                const uint32_t sc_last = (e0 + G - 1u) / c;
-                for (uint32_t sc = sc_first; sc <= sc_last && sc < (uint32_t)T_N; sc++) {
-                    const uint32_t lo = sc * c > e0 ? sc * c - e0 : 0u;
-                    const uint32_t hi_abs = (sc + 1u) * c;
-                    const uint32_t hi = hi_abs - e0 < (uint32_t)G ? hi_abs - e0 : (uint32_t)G;
-                    const uint64_t seg = ((hi - lo) >= 64u ? ~0ull : ((1ull << (hi - lo)) - 1ull)) << lo;
-                    if (badmask & seg)
-                        failmask |= 1u << sc;
-                }
-                sub++;
+                const uint32_t alive = tvalid & ~failmask; // as dealt in phase 1
+                const uint32_t width = two_width(sub, c, G, alive);
+                const uint64_t wmask = width >= 64u ? ~0ull : (1ull << width) - 1ull;
+                uint32_t rest = alive;
+                for (uint32_t ord = 0; rest; ord++, rest &= rest - 1u)
+                    if ((badmask >> (ord * width)) & wmask)
+                        failmask |= rest & (0u - rest); // lowest set bit = the ord-th surviving scenario
+                sub += width;
                 passmask = tvalid & ~failmask;
                 if (passmask == 0u) {
                     fail = true;
-                } else if (sub * G >= (uint32_t)T_N * c) {
+                } else if (sub >= c) {
                     if (__popc(passmask) == 1)
                         apply_t = __ffs(passmask) - 1;
                     else
