@@ -315,6 +315,13 @@ __device__ bool greedy_align(const GreedyLds &L, int gl, int m, int n, int nb, i
 }
 
 // look-ahead k-mers per scenario probed in the SCEN round that starts at look-ahead index `sub`
+// bit of a k-mer in the 32*G-bit visited filter of a walk
+__device__ __forceinline__ uint32_t walk_filter_index(uint64_t kmer, int G)
+{
+    const uint32_t x = (uint32_t)(kmer ^ (kmer >> 23) ^ (kmer >> 41)) * 0x9E3779B1u;
+    return x >> (32 - 5 - (G == 8 ? 3 : G == 16 ? 4 : G == 32 ? 5 : 6));
+}
+
 // index of the n-th (0-based) set bit of a small mask
 __device__ __forceinline__ uint32_t nth_bit(uint32_t mask, uint32_t n)
 {
@@ -348,7 +355,7 @@ __device__ __forceinline__ uint32_t scen_width(uint32_t sub, uint32_t c, int G, 
 template <int G, int M>
 // One fits 80 VGPRs without spilling: 6 waves per SIMD instead of 5 (the kernel waits on memory 60 % of the
 // time, measured 8 % faster); the other methods keep the compiler's own choice
-__global__ __launch_bounds__(256, (M == BRX_ONE ? 6 : 1)) void correct_kernel(PassParams p)
+__global__ __launch_bounds__(256, (M == BRX_ONE ? 6 : (M == BRX_GAP_SIZE ? 5 : 1))) void correct_kernel(PassParams p)
 {
     constexpr bool HAS_ERRLEN = (M == BRX_GRAPH || M == BRX_GAP_SIZE);
     constexpr bool HAS_ONE = (M == BRX_ONE || M == BRX_GAP_SIZE);
@@ -390,6 +397,7 @@ __global__ __launch_bounds__(256, (M == BRX_ONE ? 6 : 1)) void correct_kernel(Pa
     uint64_t tort = 0;
     uint32_t bpow = 1, blam = 0;
     bool brent = false;
+    uint32_t wfilt = 0; // this lane's 32 bits of the walk's visited-filter (exact-scan walks)
     TwoCtx tw = {0, 0, 0};
     uint32_t tvalid = 0;
     // greedy state: iteration, path length in bases, alignment offset
@@ -840,6 +848,10 @@ __global__ __launch_bounds__(256, (M == BRX_ONE ? 6 : 1)) void correct_kernel(Pa
                         // Not used when corr == first_correct_kmer (corr is never compared on entry) nor
                         // for the fixed-length walk of GapSize (a late detection could run past its end).
                         brent = (mode == MODE_GRAPH) && (corr != fc);
+                        {
+                            const uint32_t f0 = walk_filter_index(corr, G); // viewed = {corr}
+                            wfilt = ((uint32_t)gl == (f0 >> 5)) ? (1u << (f0 & 31u)) : 0u;
+                        }
                         tort = corr;
                         bpow = 1;
                         blam = 0;
@@ -911,11 +923,23 @@ __global__ __launch_bounds__(256, (M == BRX_ONE ? 6 : 1)) void correct_kernel(Pa
                             blam = 0;
                         }
                     } else {
-                        bool hit = false; // viewed_kmer.contains(&kmer): graph.rs:71, gap_size.rs:75
-                        const uint32_t stored = npath < p.maxpath ? npath : p.maxpath;
-                        for (uint32_t j = gl; j < stored; j += G)
-                            hit |= __hip_atomic_load(path + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nk;
-                        revisit = ((__ballot(hit) >> gshift) & GM) != 0ull;
+                        // viewed_kmer.contains(&kmer): graph.rs:71, gap_size.rs:75.  The visited list is scanned only
+                        // when a 32*G-bit filter spread over the group's lanes says the k-mer MAY have been seen (a
+                        // new k-mer nearly never does; always scanning costs GapSize 9 % more time, never scanning --
+                        // which would be wrong -- 4 % less)
+                        const uint32_t fidx = walk_filter_index(nk, G);
+                        const bool mine = (uint32_t)gl == (fidx >> 5);
+                        const bool maybe = ((__ballot(mine && ((wfilt >> (fidx & 31u)) & 1u)) >> gshift) & GM) != 0ull;
+                        revisit = false;
+                        if (maybe) {
+                            bool hit = false;
+                            const uint32_t stored = npath < p.maxpath ? npath : p.maxpath;
+                            for (uint32_t j = gl; j < stored; j += G)
+                                hit |= __hip_atomic_load(path + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nk;
+                            revisit = ((__ballot(hit) >> gshift) & GM) != 0ull;
+                        }
+                        if (mine)
+                            wfilt |= 1u << (fidx & 31u);
                     }
                     if (revisit) {
                         fail = true;
