@@ -652,6 +652,148 @@ __global__ __launch_bounds__(64 * P3_WAVES) void final_count_kernel(const uint16
         emit_flush();
 }
 
+// ---- final stage without a bit vector: hash-count the buckets one level earlier -------------------------------
+// When the set is only listed (lazy bit vector / sparse set) nothing forces the last radix level: a bucket of
+// 2^R hashes (R <= 20 bits left in the keys) with a few thousand keys is counted directly in an LDS hash table
+// (open addressing, entry = valid | key << 11 | count), and the entries with count > abundance are listed.  That
+// replaces the last level's histogram + scatter and the per-4096-hash counting pass.  A TEAM of 256 (one
+// workgroup) or 64 lanes (one wave) takes a bucket; a bucket with more keys than the table can take is done in
+// 2^p passes over disjoint key ranges, and a pass whose distinct keys still do not fit is repeated finer.
+constexpr uint32_t HF_VALID = 0x80000000u;
+constexpr int HF_CHUNK = 8;
+__host__ __device__ constexpr uint32_t hf_ebuf(int team) { return team > 64 ? 1024u : 512u; }
+
+template <int TEAM, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void hash_final_kernel(const uint32_t *__restrict__ keys, const uint64_t *__restrict__ off,
+                                                         uint64_t n_buckets, int R, uint32_t abundance, uint32_t log_t,
+                                                         uint64_t *__restrict__ emit_keys, uint64_t emit_cap,
+                                                         unsigned long long *__restrict__ emit_n)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t hf_lds[];
+    constexpr int TEAMS = BLOCK / TEAM;
+    constexpr uint32_t EB = hf_ebuf(TEAM);
+    const uint32_t T = 1u << log_t;
+    const int team = threadIdx.x / TEAM, tl = threadIdx.x % TEAM;
+    uint32_t *tab = (uint32_t *)hf_lds + (size_t)team * T;
+    unsigned long long *ebuf = (unsigned long long *)(hf_lds + (size_t)TEAMS * T * 4) + (size_t)team * EB;
+    uint32_t *ctl = (uint32_t *)(hf_lds + (size_t)TEAMS * T * 4 + (size_t)TEAMS * EB * 8) + team * 4; // [0] ecount, [1] overflow
+    auto team_sync = [&]() {
+        if (TEAM > 64)
+            __syncthreads();
+        else
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    };
+    auto flush = [&]() { // whole team
+        team_sync();
+        const uint32_t ne = ctl[0] < EB ? ctl[0] : EB;
+        __shared__ unsigned long long sh_base[TEAMS];
+        if (tl == 0)
+            sh_base[team] = ne ? atomicAdd(emit_n, (unsigned long long)ne) : 0ull;
+        team_sync();
+        const unsigned long long base = sh_base[team];
+        for (uint32_t q = tl; q < ne; q += TEAM)
+            if (base + q < emit_cap)
+                emit_keys[base + q] = ebuf[q];
+        team_sync();
+        if (tl == 0)
+            ctl[0] = 0;
+        team_sync();
+    };
+    if (tl == 0) {
+        ctl[0] = 0;
+        ctl[1] = 0;
+    }
+    team_sync();
+    const uint64_t n_teams = (uint64_t)gridDim.x * TEAMS;
+    for (uint64_t b = (uint64_t)blockIdx.x * TEAMS + team; b < n_buckets; b += n_teams) { // (team-uniform trip count)
+        const uint64_t s0 = off[b], n = off[b + 1] - s0;
+        if (n == 0)
+            continue;
+        // passes: 2^lp disjoint ranges of the R-bit key, each expected to hold <= 5/8 T keys
+        uint32_t lp = 0;
+        while (lp < (uint32_t)R && (n >> lp) > (uint64_t)(T / 8u * 5u))
+            lp++;
+        for (uint32_t pass = 0; pass < (1u << lp);) {
+            for (uint32_t q = tl; q < T; q += TEAM)
+                tab[q] = 0;
+            team_sync();
+            for (uint64_t i0 = 0; i0 < n; i0 += (uint64_t)TEAM * HF_CHUNK) {
+              // HF_CHUNK independent loads in flight per thread, then the (LDS-latency-bound) inserts
+              uint32_t kbuf[HF_CHUNK];
+#pragma unroll
+              for (int c = 0; c < HF_CHUNK; c++) {
+                  const uint64_t i = i0 + (uint64_t)c * TEAM + tl;
+                  kbuf[c] = i < n ? keys[s0 + i] : 0xffffffffu;
+              }
+#pragma unroll
+              for (int c = 0; c < HF_CHUNK; c++) {
+                const uint32_t key = kbuf[c];
+                if (key == 0xffffffffu || (lp && (key >> ((uint32_t)R - lp)) != pass))
+                    continue;
+                uint32_t h = (key * 0x9E3779B1u) >> (32u - log_t);
+                const uint32_t mine = HF_VALID | (key << 11);
+                for (uint32_t tries = 0;; tries++) {
+                    uint32_t e = tab[h];
+                    if (e == 0u) {
+                        e = atomicCAS(&tab[h], 0u, mine | 1u);
+                        if (e == 0u)
+                            break;
+                    }
+                    if ((e & 0xfffff800u) == mine) {
+                        if ((e & 0x7ffu) < 1024u) // saturates far above 255 and far below the key bits
+                            atomicAdd(&tab[h], 1u);
+                        break;
+                    }
+                    if (tries >= T) { // table full of other keys: this pass needs a finer split
+                        ctl[1] = 1;
+                        break;
+                    }
+                    h = (h + 1u) & (T - 1u);
+                }
+              }
+            }
+            team_sync();
+            const uint32_t ovf = ctl[1];
+            team_sync();
+            if (ovf) { // redo this key range in 4 finer passes
+                if (tl == 0)
+                    ctl[1] = 0;
+                team_sync();
+                if (lp + 2u <= (uint32_t)R) {
+                    lp += 2u;
+                    pass <<= 2;
+                    continue;
+                }
+                // cannot split further: cannot happen (2^R <= T * 2^lp by then)
+            }
+            // list the solid entries: into the team's buffer (a pass holds at most 5/8 T / (abundance + 1) of them; what
+            // does not fit goes straight to the global list), one flush per pass
+            for (uint32_t q0 = 0; q0 < T; q0 += TEAM) {
+                const uint32_t e = tab[q0 + tl];
+                const uint32_t cnt = e & 0x7ffu;
+                if ((e & HF_VALID) && (cnt > 255u ? 255u : cnt) > abundance) {
+                    const unsigned long long hk = (b << R) | (uint64_t)((e >> 11) & 0xfffffu);
+                    const uint32_t pos = atomicAdd(&ctl[0], 1u);
+                    if (pos < EB) {
+                        ebuf[pos] = hk;
+                    } else {
+                        const unsigned long long gp = atomicAdd(emit_n, 1ull);
+                        if (gp < emit_cap)
+                            emit_keys[gp] = hk;
+                    }
+                }
+            }
+            team_sync();
+            const uint32_t ec = ctl[0]; // read between two barriers: the same value in every thread
+            team_sync();
+            if (ec > EB / 2u) // one append to the global list per ~EB/2 hashes, not per bucket
+                flush();
+            pass++;
+        }
+    }
+    flush();
+}
+
 // concatenates, per level-1 bucket, the segments of every batch (only needed for > 1 batch)
 __global__ __launch_bounds__(256) void merge_segments_kernel(const uint32_t *__restrict__ src,
                                                              const uint64_t *__restrict__ src_off,
@@ -1080,7 +1222,15 @@ int part_finish_into(brx_counter *c, uint32_t abundance, hipStream_t s, brx_set 
     }
     const uint32_t *kin = keys1;
     const uint64_t *poff = l1off;
+    // no slices to write (lazy / sparse): stop one level early and hash-count the coarser buckets, if they are small
+    // enough for an LDS table (k = 19 at 1 Gbp: 131 072 buckets of ~7 600 keys with 20 bits left)
+    static const bool hf_on = [] { const char *e = getenv("BRX_HASH_FINAL"); return !(e && *e == '0'); }();
+    const int R_hf = pl.rem_in[pl.nlev - 1];
+    const uint64_t nb_hf = pl.nlev >= 2 ? pl.nchild[pl.nlev - 2] : 0;
+    const bool hash_final = hf_on && (dst->sparse || lazy) && pl.nlev >= 3 && R_hf <= 20 && total / nb_hf <= 16384;
     for (int l = 1; l < pl.nlev; l++) {
+        if (hash_final && l == pl.nlev - 1)
+            break;
         if (l == pl.nlev - 1) {
             BRX_TRY(run_level<uint16_t>(st, l, kin, poff, pl.nchild[l - 1], total, st->d_keys_fin, s, hist_tag[l], scat_tag[l]));
         } else {
@@ -1089,6 +1239,30 @@ int part_finish_into(brx_counter *c, uint32_t abundance, hipStream_t s, brx_set 
             kin = kout;
         }
         poff = st->d_coff[l];
+    }
+    if (hash_final) {
+        KernelTimer t("part_hash_final", s);
+        const uint64_t avg = total / nb_hf;
+        if (avg > 640) { // one 1024-thread workgroup per bucket, 16384-entry table
+            const uint32_t log_t = 14;
+            const size_t lds = ((size_t)4 << log_t) + hf_ebuf(1024) * 8 + 16;
+            BRX_HIP(hipFuncSetAttribute((const void *)hash_final_kernel<1024, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            const int grid = (int)(nb_hf < 256ull * 4ull ? nb_hf : 256ull * 4ull);
+            hash_final_kernel<1024, 1024><<<grid, 1024, lds, s>>>(kin, poff, nb_hf, R_hf, abundance, log_t, dst->d_keylist, dst->keylist_cap,
+                                                          dst->d_keylist_n);
+        } else { // one wave per bucket, 2048-entry table
+            const uint32_t log_t = 11;
+            const size_t lds = 4 * (((size_t)4 << log_t) + hf_ebuf(64) * 8 + 16);
+            const uint64_t want = (nb_hf + 3) / 4;
+            const int grid = (int)(want < 256ull * 16ull ? want : 256ull * 16ull);
+            hash_final_kernel<64, 256><<<grid, 256, lds, s>>>(kin, poff, nb_hf, R_hf, abundance, log_t, dst->d_keylist, dst->keylist_cap,
+                                                         dst->d_keylist_n);
+        }
+        BRX_HIP(hipGetLastError());
+        trace_stage(s, "hash final");
+        dst->keylist_valid = true;
+        dst->bits_stale = lazy;
+        return BRX_OK;
     }
     const uint64_t *fin_off = st->d_coff[pl.nlev - 1];
     {
