@@ -34,8 +34,11 @@ __global__ __launch_bounds__(256) void index_insert_kernel(const uint64_t *__res
                 L[slot] = h + 1ull;
                 break;
             }
-            if (!(seen & IDX_OVERFLOW))
-                atomicOr(L + 7, (unsigned long long)IDX_OVERFLOW);
+            {   // flag the line; at the key's home line also leave the key's signature bit
+                const unsigned long long want = (unsigned long long)IDX_OVERFLOW | (counted ? 0ull : (unsigned long long)idx_sig_bit(h + 1ull));
+                if ((seen & want) != want)
+                    atomicOr(L + 7, want);
+            }
             if (!counted) {
                 lost++;
                 counted = true;

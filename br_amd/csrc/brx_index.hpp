@@ -20,6 +20,10 @@ namespace brx {
 
 constexpr int IDX_SLOTS = 7;
 constexpr uint64_t IDX_OVERFLOW = 1ull << 63;
+// bits 32..62 of a line's header: a 31-bit signature of the keys that did not fit THEIR HOME line (the line their
+// minimizer addresses).  A probe that finds its home line flagged but its own signature bit clear is a definite
+// "absent" -- without it every probe of a flagged line, present or not, costs its group a second round.
+__host__ __device__ inline uint64_t idx_sig_bit(uint64_t key) { return 1ull << (32u + (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> 59) % 31u); }
 constexpr int IDX_MAX_M = 15; // a canonical m-mer must fit 30 bits (32-bit window arithmetic)
 
 struct IdxView {
@@ -102,7 +106,10 @@ __device__ __forceinline__ int index_probe(const IdxView &v, uint64_t fwd, int k
     // `|`, not `||`: with short-circuit evaluation the compiler loads slot 0 first and fetches the rest of
     // the line only for the lanes that did not match it -- a second, dependent memory round trip
     const bool found = (q0.x == key) | (q0.y == key) | (q1.x == key) | (q1.y == key) | (q2.x == key) | (q2.y == key) | (q3.x == key);
-    return found ? 1 : ((q3.y & IDX_OVERFLOW) ? 2 : 0);
+    // home line (hop 0): go on only if one of the keys it turned away had this key's signature; further down a
+    // chain only the flag can tell
+    const bool more = (q3.y & IDX_OVERFLOW) && (hop != 0u || (q3.y & idx_sig_bit(key)));
+    return found ? 1 : (more ? 2 : 0);
 }
 // find-or-insert of one k-mer into a chained table (sparse sets filled k-mer by k-mer, `br large-kmer`): true if the
 // key was not there.  Threads race for the first empty slot of a line with a CAS; slots never empty again, so
@@ -113,6 +120,7 @@ __device__ __forceinline__ bool table_find_or_insert(uint64_t *lines, uint32_t l
     const unsigned long long key = (((popc64(fwd) & 1) ? rc : fwd) >> 1) + 1ull;
     const uint32_t line_mask = 0xffffffffu >> line_shift;
     uint32_t line = index_line_of(minimizer_of(fwd, rc, m, w), line_shift);
+    bool first = true; // still at the key's home line
     for (;;) {
         unsigned long long *L = reinterpret_cast<unsigned long long *>(lines) + (uint64_t)line * 8ull;
         for (int j = 0; j < IDX_SLOTS; j++) {
@@ -124,8 +132,12 @@ __device__ __forceinline__ bool table_find_or_insert(uint64_t *lines, uint32_t l
             if (v == key)
                 return false;
         }
-        if (!(__hip_atomic_load(L + 7, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & IDX_OVERFLOW))
-            atomicOr(L + 7, (unsigned long long)IDX_OVERFLOW);
+        {
+            const unsigned long long want = (unsigned long long)IDX_OVERFLOW | (first ? (unsigned long long)idx_sig_bit(key) : 0ull);
+            if ((__hip_atomic_load(L + 7, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & want) != want)
+                atomicOr(L + 7, want);
+        }
+        first = false;
         line = (line + 1u) & line_mask; // the table is kept at most half full: this ends
     }
 }
