@@ -1506,10 +1506,13 @@ int brx_chain_correct_batch_device(brx_chain_t *ch, const uint8_t *d_bases, cons
                 PassParams p;
                 p.bits = no_bits(ch->set) ? nullptr : ch->set->d_bits;
                 // the index pays where whole groups probe neighbouring k-mers: One's passes and the (nearly
-                // trigger-free) reverse scans.  Walks probe 4 successors of one k-mer per round: measured
-                // 10-15 % slower through the index (Graph, GapSize forward), Greedy 78 % slower.
+                // trigger-free) reverse scans of every method; walks probe 4 successors of one k-mer per round and
+                // gain nothing from shared lines.
                 const int mth = ch->methods[m].method;
-                const bool use_idx = no_bits(ch->set) || mth == BRX_ONE || (dir == 1 && mth != BRX_GREEDY);
+                // BRX_INDEX_FWD: bit mask of the methods whose FORWARD pass probes the index; measured per method
+                // (tools/method_bench.py): One 1.4x and Greedy 5 % faster through it, Two/Graph/GapSize 2-6 % slower
+                static const unsigned idx_fwd = [] { const char *e = getenv("BRX_INDEX_FWD"); return e ? (unsigned)atoi(e) : 9u; }();
+                const bool use_idx = no_bits(ch->set) || ((idx_fwd >> mth) & 1u) || dir == 1;
                 p.idx = use_idx ? idx : IdxView{nullptr, 0, 0, 0};
                 p.k = k;
                 p.c = ch->methods[m].confirm;
