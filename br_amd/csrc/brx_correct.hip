@@ -1510,9 +1510,10 @@ int brx_chain_correct_batch_device(brx_chain_t *ch, const uint8_t *d_bases, cons
                 // gain nothing from shared lines.
                 const int mth = ch->methods[m].method;
                 // BRX_INDEX_FWD: bit mask of the methods whose FORWARD pass probes the index; measured per method
-                // (tools/method_bench.py): One 1.4x and Greedy 5 % faster through it, Two/Graph/GapSize 2-6 % slower
-                static const unsigned idx_fwd = [] { const char *e = getenv("BRX_INDEX_FWD"); return e ? (unsigned)atoi(e) : 9u; }();
-                const bool use_idx = no_bits(ch->set) || ((idx_fwd >> mth) & 1u) || dir == 1;
+                // (tools/method_bench.py, 1 Gbp): One 1.4x faster through it, Two/Graph/GapSize 2-6 % slower, Greedy
+                // 5 % faster at 1 Gbp but 8 % slower at 10 Gbp (200 M keys)
+                static const unsigned idx_fwd = [] { const char *e = getenv("BRX_INDEX_FWD"); return e ? (unsigned)atoi(e) : 1u; }();
+                const bool use_idx = no_bits(ch->set) || ((idx_fwd >> mth) & 1u) || (dir == 1 && mth != BRX_GREEDY);
                 p.idx = use_idx ? idx : IdxView{nullptr, 0, 0, 0};
                 p.k = k;
                 p.c = ch->methods[m].confirm;
