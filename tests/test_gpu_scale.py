@@ -181,3 +181,73 @@ def test_more_than_2_31_kmers_in_one_counter():
     assert solid.get_many(rnd).mean() < 0.01
     kl = solid.keylist_device(stream)
     assert kl is not None and kl[1] == n_solid
+
+
+def test_hash_final_skewed_buckets():
+    """the LDS hash-count of the partitioned finish on hand-made keys (fed through the exchange entry
+    add_partitioned_device): one level-2 bucket with 40 000 DISTINCT hashes that all fall into the first quarter of
+    its key range (more than the table holds: the pass is redone on finer ranges, and the solid hashes outnumber the
+    workgroup's list buffer), a bucket with one hash repeated 300 000 times (many passes, a saturated count), and a
+    sprinkle of ordinary keys.  Checked against the counts computed on the host."""
+    import torch
+    k = 19
+    stream = torch.cuda.current_stream().cuda_stream
+    rng = np.random.default_rng(11)
+    nb1 = 512  # first digit: 9 bits; level-1 keys: 28 bits = 8-bit second digit | 20-bit rest
+    def key32(d2, rest):
+        return (np.uint32(d2) << np.uint32(20)) | rest.astype(np.uint32)
+    parts = {}
+    dense = np.arange(40_000, dtype=np.uint32)                      # rest < 2^18: all in the first of 4 ranges
+    parts[5] = np.concatenate([key32(7, dense), key32(7, dense[:1000]), key32(7, dense[:1000]),   # 1000 of them 3x
+                               key32(9, np.full(300_000, 123, dtype=np.uint32))])
+    parts[300] = np.concatenate([key32(d, rng.integers(0, 1 << 20, 2000)) for d in (0, 255)] * 2)  # every key twice
+    keys, l1off = [], np.zeros(nb1 + 1, dtype=np.int64)
+    for b in range(nb1):
+        ks = parts.get(b, np.zeros(0, dtype=np.uint32))
+        keys.append(rng.permutation(ks))
+        l1off[b + 1] = l1off[b] + len(ks)
+    keys = np.concatenate(keys)
+    want = {}
+    for b, ks in parts.items():
+        for v in ks.tolist():
+            h = (b << 28) | v
+            want[h] = want.get(h, 0) + 1
+    dk = torch.from_numpy(keys.view(np.int32).copy()).cuda()
+    do = torch.from_numpy(l1off).cuda()
+    # a second key set: the same special buckets under a background of 92 M single (a few double) random keys in the
+    # other first digits, which lifts the average bucket over the threshold where one workgroup takes a bucket
+    per = 181_000
+    g = torch.Generator(device="cuda").manual_seed(3)
+    segs, off_bg, pos = [], np.zeros(nb1 + 1, dtype=np.int64), 0
+    for b in range(nb1):
+        if b in parts:
+            seg = dk[int(l1off[b]):int(l1off[b + 1])]
+        else:
+            seg = torch.randint(0, 1 << 28, (per,), generator=g, device="cuda", dtype=torch.int32)
+        segs.append(seg)
+        pos += seg.numel()
+        off_bg[b + 1] = pos
+    dk_bg, do_bg = torch.cat(segs), torch.from_numpy(off_bg).cuda()
+    for abundance, with_bg in ((0, False), (2, False), (200, False), (2, True), (200, True)):
+        cnt = br_amd.Counter(k, 0, _lib.COUNT_SORTED)
+        if with_bg:
+            cnt.add_partitioned_device(dk_bg.data_ptr(), do_bg.data_ptr(), dk_bg.numel())
+        else:
+            cnt.add_partitioned_device(dk.data_ptr(), do.data_ptr(), dk.numel())
+        gs = br_amd.Pcon.new(k)
+        cnt.finish_into(abundance, gs, stream)
+        torch.cuda.synchronize()
+        assert gs.bits_state() == 1
+        solid = sorted(h for h, c in want.items() if min(c, 255) > abundance)
+        kl = gs.keylist_device(stream)
+        assert kl is not None
+        if with_bg:  # background keys seen 3+ times are solid too at abundance 2 (a handful): compare the special buckets
+            allk = bd.device_view(kl[0], max(kl[1], 1) * 8).view(torch.int64)[:kl[1]].cpu().numpy()
+            got = allk[np.isin(allk >> 28, list(parts))]
+            assert np.array_equal(np.sort(got), np.array(solid, dtype=np.int64))
+            assert kl[1] - len(got) < (200 if abundance == 2 else 1)
+            continue
+        assert kl[1] == len(solid)
+        got = bd.device_view(kl[0], max(kl[1], 1) * 8).view(torch.int64)[:kl[1]].cpu().numpy()
+        assert np.array_equal(np.sort(got), np.array(solid, dtype=np.int64))
+        assert gs.popcount() == len(solid)
