@@ -1220,13 +1220,27 @@ __global__ __launch_bounds__(256) void compact_kernel(const uint8_t *__restrict_
         const uint8_t *src = stage + slot_of(offsets[r], r, slack);
         const uint32_t n = lens[r];
         uint8_t *dst = out + out_offsets[r];
-        if (reversed) {
-            for (uint32_t j = threadIdx.x; j < n; j += blockDim.x)
-                dst[j] = src[n - 1u - j];
-        } else {
-            for (uint32_t j = threadIdx.x; j < n; j += blockDim.x)
-                dst[j] = src[j];
+        // bytes up to the first 16-byte boundary of dst, then 16 bytes per lane (unaligned load, byte order reversed
+        // in registers when the staged read is stored back to front, aligned store), then the tail
+        uint32_t head = (uint32_t)((16u - (uint32_t)((uintptr_t)dst & 15u)) & 15u);
+        if (head > n)
+            head = n;
+        const uint32_t nv = (n - head) / 16u;
+        for (uint32_t j = threadIdx.x; j < head; j += blockDim.x)
+            dst[j] = reversed ? src[n - 1u - j] : src[j];
+        for (uint32_t v = threadIdx.x; v < nv; v += blockDim.x) {
+            const uint32_t j = head + 16u * v;
+            uint4 q;
+            if (reversed) {
+                __builtin_memcpy(&q, src + (n - 16u - j), 16);
+                q = make_uint4(__builtin_bswap32(q.w), __builtin_bswap32(q.z), __builtin_bswap32(q.y), __builtin_bswap32(q.x));
+            } else {
+                __builtin_memcpy(&q, src + j, 16);
+            }
+            *reinterpret_cast<uint4 *>(dst + j) = q;
         }
+        for (uint32_t j = head + 16u * nv + threadIdx.x; j < n; j += blockDim.x)
+            dst[j] = reversed ? src[n - 1u - j] : src[j];
     }
 }
 
