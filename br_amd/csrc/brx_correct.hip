@@ -404,7 +404,10 @@ __global__ __launch_bounds__(256, (M == BRX_ONE ? 6 : (M == BRX_GAP_SIZE ? 5 : 1
     uint32_t git = 0, gnl = 0, steps = 0;
     int goff = 0;
     // statistics
+    // per-wave totals (wave-uniform, so they live in scalar registers instead of four VGPRs of a kernel that is at its
+    // register limit): the lanes note their events of a round in `ev`, the end of the round ballots them
     uint32_t n_rounds = 0, n_probes = 0, n_trig = 0, n_fix = 0;
+    enum { EV_ROUND = 1, EV_PROBE = 2, EV_TRIG = 4, EV_FIX = 8 };
 
     auto fetch = [&]() {
         for (;;) {
@@ -508,6 +511,7 @@ __global__ __launch_bounds__(256, (M == BRX_ONE ? 6 : (M == BRX_GAP_SIZE ? 5 : 1
     fetch();
 
     while (__any(have)) {
+        uint32_t ev = 0;
         bool do_probe = false;
         uint64_t pk = 0;
         uint8_t ch = 0;
@@ -516,7 +520,7 @@ __global__ __launch_bounds__(256, (M == BRX_ONE ? 6 : (M == BRX_GAP_SIZE ? 5 : 1
 
         // ---------------- phase 1: choose this round's probe --------------------------------
         if (have) {
-            n_rounds += (gl == 0);
+            ev |= (gl == 0) ? EV_ROUND : 0u;
             if (st == ST_INIT) {
                 if (n < (uint32_t)k) {
                     // mod.rs:56-58: shorter than k, returned verbatim (cap >= n + 64 always)
@@ -690,7 +694,7 @@ __global__ __launch_bounds__(256, (M == BRX_ONE ? 6 : (M == BRX_GAP_SIZE ? 5 : 1
                     const int pr = index_probe(p.idx, pk, k);
                     sol = pr == 1;
                     unres = pr == 2;
-                    n_probes++;
+                    ev |= EV_PROBE;
                 } else if (was_unres) {
                     if (p.bits) {
                         sol = probe(p.bits, pk, k);
@@ -699,7 +703,7 @@ __global__ __launch_bounds__(256, (M == BRX_ONE ? 6 : (M == BRX_GAP_SIZE ? 5 : 1
                         sol = pr == 1;
                         unres = pr == 2;
                     }
-                    n_probes++;
+                    ev |= EV_PROBE;
                 } else {
                     sol = kept_sol; // answered by the index in the round being repeated
                 }
@@ -711,7 +715,7 @@ __global__ __launch_bounds__(256, (M == BRX_ONE ? 6 : (M == BRX_GAP_SIZE ? 5 : 1
             kept_sol = sol;
         } else if (do_probe) {
             sol = probe(p.bits, pk, k);
-            n_probes++;
+            ev |= EV_PROBE;
         }
         const uint64_t ball = __ballot(sol);
         const uint64_t gmask = (ball >> gshift) & GM;
@@ -750,7 +754,7 @@ __global__ __launch_bounds__(256, (M == BRX_ONE ? 6 : (M == BRX_GAP_SIZE ? 5 : 1
                     if (trig) {
                         kmer = __shfl(pk, gshift + (int)nacc);
                         ch_t = (uint8_t)__shfl((int)ch, gshift + (int)nacc);
-                        n_trig += (gl == 0);
+                        ev |= (gl == 0) ? EV_TRIG : 0u;
                         if (HAS_ERRLEN) {
                             st = ST_ERRLEN;
                             ej = 0;
@@ -1083,7 +1087,7 @@ __global__ __launch_bounds__(256, (M == BRX_ONE ? 6 : (M == BRX_GAP_SIZE ? 5 : 1
                         prev = true;
                         const long long ni = (long long)i + (long long)gnl + (long long)goff;
                         i = (ni < 0 || ni > (long long)n) ? n : (uint32_t)ni;
-                        n_fix += (gl == 0);
+                        ev |= (gl == 0) ? EV_FIX : 0u;
                         if (i >= n)
                             finish();
                         else
@@ -1124,7 +1128,7 @@ __global__ __launch_bounds__(256, (M == BRX_ONE ? 6 : (M == BRX_GAP_SIZE ? 5 : 1
                     kmer = corr;
                     prev = true;
                     i += 2u - (uint32_t)apply_s;
-                    n_fix += (gl == 0);
+                    ev |= (gl == 0) ? EV_FIX : 0u;
                     // The c look-ahead k-mers of the winning scenario ARE the next c scan k-mers and were
                     // all found solid: the reference's loop would copy these c bases with previous = true
                     // (mod.rs:99-102).  Accept them without probing again.
@@ -1159,7 +1163,7 @@ __global__ __launch_bounds__(256, (M == BRX_ONE ? 6 : (M == BRX_GAP_SIZE ? 5 : 1
                     kmer = km;
                     prev = true;
                     i += offc;
-                    n_fix += (gl == 0);
+                    ev |= (gl == 0) ? EV_FIX : 0u;
                     if (i >= n)
                         finish();
                     else
@@ -1176,7 +1180,7 @@ __global__ __launch_bounds__(256, (M == BRX_ONE ? 6 : (M == BRX_GAP_SIZE ? 5 : 1
                     kmer = wk;
                     prev = true;
                     i += path_offset;
-                    n_fix += (gl == 0);
+                    ev |= (gl == 0) ? EV_FIX : 0u;
                     if (i >= n)
                         finish();
                     else
@@ -1184,30 +1188,24 @@ __global__ __launch_bounds__(256, (M == BRX_ONE ? 6 : (M == BRX_GAP_SIZE ? 5 : 1
                 }
             }
         }
+        // end of the round, every lane back together: count the events
+        n_rounds += (uint32_t)__builtin_popcountll(__ballot(ev & EV_ROUND));
+        n_probes += (uint32_t)__builtin_popcountll(__ballot(ev & EV_PROBE));
+        n_trig += (uint32_t)__builtin_popcountll(__ballot(ev & EV_TRIG));
+        n_fix += (uint32_t)__builtin_popcountll(__ballot(ev & EV_FIX));
     }
 
     // statistics: one atomic per wave per counter
-    uint32_t v;
-    v = n_rounds;
-    for (int d = 32; d > 0; d >>= 1)
-        v += __shfl_down(v, d);
-    if (lane == 0 && v)
-        atomicAdd(p.ctrl + CTL_ROUNDS, (unsigned long long)v);
-    v = n_probes;
-    for (int d = 32; d > 0; d >>= 1)
-        v += __shfl_down(v, d);
-    if (lane == 0 && v)
-        atomicAdd(p.ctrl + CTL_PROBES, (unsigned long long)v);
-    v = n_trig;
-    for (int d = 32; d > 0; d >>= 1)
-        v += __shfl_down(v, d);
-    if (lane == 0 && v)
-        atomicAdd(p.ctrl + CTL_TRIGGERS, (unsigned long long)v);
-    v = n_fix;
-    for (int d = 32; d > 0; d >>= 1)
-        v += __shfl_down(v, d);
-    if (lane == 0 && v)
-        atomicAdd(p.ctrl + CTL_FIXES, (unsigned long long)v);
+    if (lane == 0) {
+        if (n_rounds)
+            atomicAdd(p.ctrl + CTL_ROUNDS, (unsigned long long)n_rounds);
+        if (n_probes)
+            atomicAdd(p.ctrl + CTL_PROBES, (unsigned long long)n_probes);
+        if (n_trig)
+            atomicAdd(p.ctrl + CTL_TRIGGERS, (unsigned long long)n_trig);
+        if (n_fix)
+            atomicAdd(p.ctrl + CTL_FIXES, (unsigned long long)n_fix);
+    }
 }
 
 // one workgroup per read (grid-stride): staged slot -> compact output, reversing if needed
