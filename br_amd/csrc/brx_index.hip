@@ -75,40 +75,6 @@ __global__ void index_get_kernel(IdxView v, const uint32_t *__restrict__ bits, c
     out[i] = (uint8_t)r;
 }
 
-// presence-only fill of a sparse set: every k-mer of every read of length >= k (Hash::from_fasta, src/set/hash.rs:40-60)
-constexpr int INS_STRIP = 32;
-__global__ __launch_bounds__(256) void table_insert_reads_kernel(const uint8_t *__restrict__ bases, const uint64_t *__restrict__ offsets,
-                                                                 uint32_t n_reads, int k, uint64_t *__restrict__ lines, uint32_t line_shift,
-                                                                 uint32_t m, uint32_t w, unsigned long long *__restrict__ n_new)
-{
-    const uint64_t mask = kmask(k);
-    uint32_t added = 0;
-    for (uint32_t r = blockIdx.x; r < n_reads; r += gridDim.x) {
-        const uint64_t s = offsets[r];
-        const uint64_t len = offsets[r + 1] - s;
-        if (len < (uint64_t)k)
-            continue;
-        const uint64_t nk = len - (uint64_t)k + 1;
-        const uint8_t *seq = bases + s;
-        for (uint64_t p0 = (uint64_t)threadIdx.x * INS_STRIP; p0 < nk; p0 += (uint64_t)blockDim.x * INS_STRIP) {
-            uint64_t kmer = 0;
-            for (int j = 0; j < k; j++)
-                kmer = (kmer << 2) | nuc2bit(seq[p0 + j]);
-            const uint64_t pend = (p0 + INS_STRIP < nk) ? p0 + INS_STRIP : nk;
-            for (uint64_t p = p0;;) {
-                added += table_find_or_insert(lines, line_shift, m, w, k, kmer) ? 1u : 0u;
-                if (++p >= pend)
-                    break;
-                kmer = add_nuc(kmer, nuc2bit(seq[p + k - 1]), mask);
-            }
-        }
-    }
-    for (int d = 32; d > 0; d >>= 1)
-        added += __shfl_down(added, d);
-    if ((threadIdx.x & 63) == 0 && added)
-        atomicAdd(n_new, (unsigned long long)added);
-}
-
 // moves every key of one table into another (growing an insert-built set)
 __global__ __launch_bounds__(256) void table_rehash_kernel(const uint64_t *__restrict__ old_lines, uint64_t n_old_lines, int k,
                                                            uint64_t *__restrict__ lines, uint32_t line_shift, uint32_t m, uint32_t w)
@@ -332,10 +298,12 @@ int index_insert_reads(brx_set *set, const uint8_t *d_bases, const uint64_t *d_o
     hipError_t e = hipMemsetAsync(d_new, 0, 8, s);
     if (e == hipSuccess && n_reads) {
         KernelTimer t("index_insert_reads", s);
-        const uint32_t grid = n_reads < (1u << 16) ? n_reads : (1u << 16);
-        table_insert_reads_kernel<<<grid, 256, 0, s>>>(d_bases, d_offsets, n_reads, k, set->d_lines, 32u - set->idx_log_lines,
-                                                       set->idx_m, (uint32_t)k - set->idx_m + 1u, d_new);
-        e = hipGetLastError();
+        int st = flat_presence_insert(d_bases, d_offsets, n_reads, total_bases, k, nullptr, set->d_lines, 32u - set->idx_log_lines,
+                                      set->idx_m, d_new, s);
+        if (st != BRX_OK) {
+            (void)hipFree(d_new);
+            return st;
+        }
     }
     unsigned long long added = 0;
     if (e == hipSuccess)

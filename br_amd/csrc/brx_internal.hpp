@@ -94,6 +94,9 @@ struct IdxView;
 int index_build_from_keys(brx_set *set, const uint64_t *d_keys, uint64_t n, int m, int log_lines, hipStream_t s);
 int index_insert_reads(brx_set *set, const uint8_t *d_bases, const uint64_t *d_offsets, uint32_t n_reads, uint64_t total_bases,
                        hipStream_t s);
+// presence-only insertion over the flat base stream (brx_partbuild.hip); table == nullptr: atomicOr into `bits`
+int flat_presence_insert(const uint8_t *d_bases, const uint64_t *d_offsets, uint32_t n_reads, uint64_t total_bases, int k,
+                         uint32_t *bits, uint64_t *table, uint32_t line_shift, uint32_t m, unsigned long long *d_new, hipStream_t s);
 // sets of this k have no bit vector
 inline bool sparse_k(int k) { return k >= 21; }
 // the set must be probed through its (chained) index: it has no bit vector, or not right now

@@ -26,6 +26,7 @@
 // matrices.  HBM traffic for k=19: ~30 B per k-mer + one 16 GiB bitset write, instead of 129 B
 // per k-mer + 2 x 128 GiB.
 #include "brx_internal.hpp"
+#include "brx_index.hpp"
 
 #include <stdlib.h>
 #include <string.h>
@@ -204,6 +205,42 @@ __global__ __launch_bounds__(256) void l1_hist_kernel(L1Args a)
         for (uint32_t b = threadIdx.x; b < B; b += 256)
             a.matrix[(uint64_t)b * a.n_items + item] = lds[b];
         __syncthreads();
+    }
+}
+
+// presence-only insertion over the FLAT base stream (Pcon::from_fasta / Hash::from_fasta): the same tiles and
+// read-boundary bitmap as the level-1 partition, so one 250 Mbp record keeps the whole chip busy instead of
+// one workgroup.  TABLE = false: atomicOr into the bit vector; TABLE = true: find-or-insert into the chained
+// table of a sparse set (n_new counts the k-mers that were not there yet).
+template <bool TABLE>
+__global__ __launch_bounds__(256) void flat_insert_kernel(L1Args a, uint32_t *__restrict__ bits, uint64_t *__restrict__ lines,
+                                                          uint32_t line_shift, uint32_t m, uint32_t w,
+                                                          unsigned long long *__restrict__ n_new)
+{
+    __shared__ uint32_t pk[PACK_WORDS];
+    __shared__ uint32_t bnd[BND_WORDS];
+    __shared__ uint32_t sh_r0;
+    uint32_t added = 0;
+    for (uint32_t item = blockIdx.x; item < a.n_items; item += gridDim.x) {
+        uint32_t n_here;
+        l1_prepare(a, item, pk, bnd, &sh_r0, n_here);
+        for (uint32_t p = threadIdx.x; p < n_here; p += 256)
+            if (l1_valid(bnd, p, a.k)) {
+                const uint64_t kmer = kmer_at(pk, p, a.k);
+                if (TABLE) {
+                    added += table_find_or_insert(lines, line_shift, m, w, a.k, kmer) ? 1u : 0u;
+                } else {
+                    const uint64_t h = khash(kmer, a.k);
+                    atomicOr(bits + (h >> 5), 1u << (h & 31u));
+                }
+            }
+        __syncthreads();
+    }
+    if (TABLE) {
+        for (int d = 32; d > 0; d >>= 1)
+            added += __shfl_down(added, d);
+        if ((threadIdx.x & 63) == 0 && added)
+            atomicAdd(n_new, (unsigned long long)added);
     }
 }
 
@@ -877,6 +914,34 @@ static int ensure_dev(void **p, uint64_t *cap, uint64_t need_bytes)
         return BRX_ERR_NOMEM;
     }
     *cap = want;
+    return BRX_OK;
+}
+
+// presence-only insertion of a batch (see flat_insert_kernel); table == nullptr: into `bits`
+int flat_presence_insert(const uint8_t *d_bases, const uint64_t *d_offsets, uint32_t n_reads, uint64_t total_bases, int k,
+                         uint32_t *bits, uint64_t *table, uint32_t line_shift, uint32_t m, unsigned long long *d_new, hipStream_t s)
+{
+    if (!total_bases || !n_reads)
+        return BRX_OK;
+    const uint64_t n_items64 = (total_bases + L1_TILE - 1) / L1_TILE;
+    if (n_items64 >= (1ull << 32)) {
+        set_error("batch of %llu bases is too large for one insertion pass; split it", (unsigned long long)total_bases);
+        return BRX_ERR_UNSUPPORTED;
+    }
+    L1Args a;
+    memset(&a, 0, sizeof(a));
+    a.bases = d_bases;
+    a.offsets = d_offsets;
+    a.n_reads = n_reads;
+    a.total = total_bases;
+    a.n_items = (uint32_t)n_items64;
+    a.k = k;
+    const int grid = a.n_items < 4096u ? (int)a.n_items : 4096;
+    if (table)
+        flat_insert_kernel<true><<<grid, 256, 0, s>>>(a, nullptr, table, line_shift, m, (uint32_t)k - m + 1u, d_new);
+    else
+        flat_insert_kernel<false><<<grid, 256, 0, s>>>(a, bits, nullptr, 0, 0, 0, nullptr);
+    BRX_HIP(hipGetLastError());
     return BRX_OK;
 }
 

@@ -470,7 +470,7 @@ int brx_set_insert_batch(brx_set_t *set, const uint8_t *bases, const uint64_t *o
     int st = upload_batch(bases, offsets, n_reads, &d_b, &bc, &d_o, &oc, &tot, 0);
     if (st == BRX_OK) {
         KernelTimer t("insert", 0);
-        kmer_scatter_kernel<1><<<grid_for(n_reads, 1, 1 << 20), 256, 0, 0>>>(d_b, d_o, n_reads, set->k, set->d_bits);
+        st = flat_presence_insert(d_b, d_o, n_reads, tot, set->k, set->d_bits, nullptr, 0, 0, nullptr, 0);
     }
     hipError_t e = hipDeviceSynchronize();
     if (d_b)
@@ -504,9 +504,8 @@ int brx_set_insert_batch_device(brx_set_t *set, const uint8_t *d_bases, const ui
     index_invalidate(set);
     {
         KernelTimer t("insert", s);
-        kmer_scatter_kernel<1><<<grid_for(n_reads, 1, 1 << 20), 256, 0, s>>>(d_bases, d_offsets, n_reads, set->k, set->d_bits);
+        BRX_TRY(flat_presence_insert(d_bases, d_offsets, n_reads, total_bases, set->k, set->d_bits, nullptr, 0, 0, nullptr, s));
     }
-    BRX_HIP(hipGetLastError());
     return BRX_OK;
 }
 

@@ -155,3 +155,29 @@ def test_large_kmer_cli(tmp_path, golden_dir, raw_reads):
     assert got == raw_reads and ref.popcount() > 0
     with pytest.raises(SystemExit):
         cli.main(["-i", src, "-o", str(dst), "large-kmer", "-i", src, "-f", "fasta", "-k", "24"])
+
+
+@pytest.mark.parametrize("k", [15, 23])
+def test_presence_insert_one_long_record(k):
+    """`solid -f fasta` / `large-kmer` on genome-like input: a single 1.5 Mbp record (plus records shorter than k and
+    an empty one) is spread over the whole chip by tiles of the flat base stream; same set as the oracle's"""
+    cfg = synth.config(genome_len=1_500_000, read_len=1000)
+    g = synth.genome_host(cfg).tobytes()
+    recs = [b"ACGT", g, b"", b"ACGTACGTACGTAC", g[1000:1000 + k], g[5000:5000 + k - 1]]
+    gs = br_amd.Pcon.from_fasta(recs, k)
+    if k == 15:
+        ref = O.Solid(k)
+        for r in recs:
+            if len(r) >= k:
+                ref.set_seq(r)
+        assert gs.to_solid_bytes() == ref.to_bytes()
+    else:
+        assert gs.is_sparse()
+        ref = O.Solid.sparse_from_count(k, recs, 0)
+        assert gs.popcount() == ref.popcount()
+        rng = np.random.default_rng(2)
+        starts = rng.integers(0, len(g) - k, 4000)
+        q = np.array([O.seq2bit(g[s:s + k]) for s in starts] + rng.integers(0, 1 << (2 * k), 4000, dtype=np.uint64).tolist(),
+                     dtype=np.uint64)
+        want = np.array([ref.get(int(x)) for x in q])
+        assert np.array_equal(gs.get_many(q), want) and want[:4000].all()
