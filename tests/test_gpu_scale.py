@@ -133,9 +133,9 @@ def test_sample_of_reads_matches_oracle(job):
     d_out = torch.empty(int(job["total"] * 1.05) + (1 << 20), dtype=torch.uint8, device="cuda")
     d_oo = torch.empty(N_READS + 1, dtype=torch.int64, device="cuda")
     rng = np.random.default_rng(5)
-    sample = sorted(set(rng.integers(0, N_READS, size=120).tolist()) | {0, N_READS - 1})
+    sample = sorted(set(rng.integers(0, N_READS, size=60).tolist()) | {0, N_READS - 1})
     off_h = job["offsets"].cpu().numpy()
-    for methods in (["one"], ["one", "graph"]):
+    for methods in (["one"], ["one", "graph"], ["two"], ["greedy"], ["gap_size"]):
         chain = br_amd.Chain(job["solid"], [(m, 5, 7) for m in methods], two_side=False)
         tot = chain.correct_batch_device(job["bases"].data_ptr(), job["offsets"].data_ptr(), N_READS, job["total"],
                                          d_out.data_ptr(), d_out.numel(), d_oo.data_ptr(), stream)
@@ -147,7 +147,7 @@ def test_sample_of_reads_matches_oracle(job):
             got = d_out[int(oo_h[r]):int(oo_h[r + 1])].cpu().numpy().tobytes()
             assert got == O.correct_record(om, src, False), (methods, r)
         st = chain.last_stats()
-        assert st["fixes"] > 10_000_000
+        assert st["fixes"] > (10_000_000 if methods[0] in ("one", "gap_size") else 500_000)
 
 
 def test_more_than_2_31_kmers_in_one_counter():
