@@ -1114,7 +1114,10 @@ int part_add_batch(brx_counter *c, const uint8_t *d_bases, const uint64_t *d_off
     l1_coff_kernel<<<(B + 1 + 255) / 256, 256, 0, s>>>(st->d_pos, B, n_items, b.d_l1off);
     {
         KernelTimer t("part_l1_scatter", s);
-        l1_scatter_kernel<<<grid, 256, scatter_lds_bytes(L1_TILE, a.bits), s>>>(a);
+        const size_t lds1 = scatter_lds_bytes(L1_TILE, a.bits);
+        if (lds1 > 64 * 1024)
+            BRX_HIP(hipFuncSetAttribute((const void *)l1_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
+        l1_scatter_kernel<<<grid, 256, lds1, s>>>(a);
     }
     trace_stage(s, "partition level 1: scatter");
     BRX_HIP(hipGetLastError());
