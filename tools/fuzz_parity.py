@@ -51,7 +51,7 @@ t_end = time.time() + budget
 case = 0
 while time.time() < t_end:
     case += 1
-    k = int(rng.choice([5, 7, 9, 11, 13, 15, 17]))
+    k = int(rng.choice([5, 7, 9, 11, 13, 15, 17, 19, 21, 25]))
     a = int(rng.choice([0, 1, 2, 3]))
     c = int(rng.choice([0, 1, 2, 5, 9]))
     ms = int(rng.choice([1, 3, 7, 12]))
@@ -72,15 +72,23 @@ while time.time() < t_end:
         else:
             os.environ[key] = v
     os.environ["BRX_GROUP_REV"] = os.environ.get("BRX_GROUP", "") or "64"
-    strategy = _lib.COUNT_SORTED if (k >= 7 and rng.random() < 0.7) else _lib.COUNT_DENSE
+    strategy = _lib.COUNT_SORTED if (k >= 17 or (k >= 7 and rng.random() < 0.7)) else _lib.COUNT_DENSE
+    if k > 21:
+        continue_presence = True  # counting stops at k = 21: larger k are presence-only (large-kmer) sets
+    else:
+        continue_presence = False
     if strategy == _lib.COUNT_DENSE:
         os.environ["BRX_FORCE_SPARSE"] = "0"
     counted = [r for r in reads]
-    cnt = br_amd.Counter(k, 0, strategy)
-    if counted:
-        cnt.add_reads(counted)
-    gs = cnt.finish(a)
-    ref = O.Solid.from_count(k, O.count_reads(k, counted), a)
+    if continue_presence:
+        a = 0
+        gs = br_amd.Pcon.from_fasta(counted, k, batch=int(rng.choice([3, 50, 8192])))
+    else:
+        cnt = br_amd.Counter(k, 0, strategy)
+        if counted:
+            cnt.add_reads(counted)
+        gs = cnt.finish(a)
+    ref = O.Solid.sparse_from_count(k, counted, a) if k >= 17 else O.Solid.from_count(k, O.count_reads(k, counted), a)
     desc = f"case {case}: k={k} a={a} c={c} ms={ms} reads={n_reads} chain={names} two_side={two_side} strat={strategy} {env}"
     if gs.popcount() != ref.popcount():
         print("SET MISMATCH", desc); sys.exit(1)
