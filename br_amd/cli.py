@@ -7,10 +7,9 @@
 
 Same flags, defaults and quirks as the reference: `-s/--two-side` DISABLES the reverse pass
 (src/lib.rs:48,110); `fasta -k` is forced odd (src/cli.rs:277-279); without `-a` an abundance method
-sub-command is needed (src/main.rs:95-110).  `first-minimum` is implemented from pcon's published
-algorithm (first index where the count spectrum rises; unpinned by the reference's tests);
-`rarefaction` / `percent-most` / `percent-least` and the `count` sub-command (pcon count files) are rows
-N2-N3 of SURVEY 8(f) and fail loudly here; `large-kmer -f fasta` (N4) builds a sparse set for odd k <= 31.  `-t` (rayon
+sub-command is needed (src/main.rs:95-110): `first-minimum`, `rarefaction P`, `percent-most P`, `percent-least P`
+pick the threshold from the count spectrum (br_amd/spectrum.py: pcon's published formulas, unpinned by the
+reference's tests).  The `count` sub-command (pcon count files, row N3 of SURVEY 8(f)) fails loudly here; `large-kmer -f fasta` (N4) builds a sparse set for odd k <= 31.  `-t` (rayon
 pool size) is accepted and ignored: the GPU is the pool.
 """
 from __future__ import annotations
@@ -23,7 +22,7 @@ import lzma
 import sys
 from typing import BinaryIO, List, Optional
 
-from . import _lib, fasta
+from . import _lib, fasta, spectrum
 from .correct import build_methods
 from .driver import run_correction
 from .set import Counter, Pcon
@@ -95,12 +94,7 @@ def fasta_kmer_size(k: int) -> int:
     return k - ((~(k & 1)) & 1)
 
 
-def first_minimum(spectrum) -> Optional[int]:
-    """pcon::spectrum ThresholdMethod::FirstMinimum: first index i with spectrum[i+1] > spectrum[i]."""
-    for i in range(len(spectrum) - 1):
-        if int(spectrum[i + 1]) > int(spectrum[i]):
-            return i
-    return None
+first_minimum = spectrum.first_minimum
 
 
 def _records(paths: List[str]):
@@ -120,19 +114,18 @@ def build_set(args) -> Pcon:
                 with open_input(path) as f:
                     cnt.count_fasta(f)
             return cnt.finish(args.abundance)
-        if args.abundance_selection == "first-minimum":
-            cnt = Counter(k, dev, _lib.COUNT_DENSE)  # the spectrum needs the u8 table
-            for path in args.sub_inputs:
-                with open_input(path) as f:
-                    cnt.count_fasta(f)
-            thr = first_minimum(cnt.spectrum())
-            if thr is None:
-                raise SystemExit("Error: Can't compute minimal abundance")          # error.rs ComputeAbundanceThreshold
-            return cnt.finish(thr)
         if args.abundance_selection is None:
             raise SystemExit("Error: You must provide an abundance method or an abundance threshold")  # main.rs:109
-        raise SystemExit(f"abundance method {args.abundance_selection!r} is not implemented on the HIP path "
-                         "(pcon::spectrum formula unpinned, SURVEY 8(f) N2); pass -a N")
+        # count once, histogram the counts on the GPU (no u8 table: the partitioned keys are binned bucket by
+        # bucket), pick the threshold on the host, then finish the same counter with it (src/main.rs:93-114)
+        cnt = Counter(k, dev)
+        for path in args.sub_inputs:
+            with open_input(path) as f:
+                cnt.count_fasta(f)
+        thr = spectrum.get_threshold(cnt.spectrum(), args.abundance_selection, getattr(args, "percent", 0.0))
+        if thr is None:
+            raise SystemExit("Error: Can't compute minimal abundance")              # error.rs ComputeAbundanceThreshold
+        return cnt.finish(thr)
     if args.subcommand == "solid":
         if args.format == "solid":
             with open_input(args.sub_input) as f:

@@ -831,6 +831,42 @@ __global__ __launch_bounds__(BLOCK) void hash_final_kernel(const uint32_t *__res
     flush();
 }
 
+// ---- count spectrum without the u8 table (pcon::spectrum::Spectrum::from_count, src/main.rs:93) ----------------
+// One wave per last-level bucket (2^F_BITS hashes, u16 keys): count the keys in LDS, then every key swaps its
+// counter for 0 -- exactly one lane per distinct hash gets the count and bins min(count, 255), pcon's saturated
+// u8.  Bin 0 (hashes never seen) is 2^(2k-1) minus the rest; the host fills it in.
+constexpr int SP_WAVES = 4;
+__global__ __launch_bounds__(64 * SP_WAVES) void final_spectrum_kernel(const uint16_t *__restrict__ keys, const uint64_t *__restrict__ off,
+                                                                       uint64_t n_buckets, unsigned long long *__restrict__ hist)
+{
+    __shared__ uint32_t sp_cnt[SP_WAVES][F_SIZE];
+    __shared__ unsigned long long sp_hist[256];
+    const int wave = threadIdx.x / 64, lane = threadIdx.x % 64;
+    uint32_t *cnt = sp_cnt[wave];
+    for (uint32_t q = lane; q < F_SIZE; q += 64)
+        cnt[q] = 0;
+    for (uint32_t q = threadIdx.x; q < 256; q += 64 * SP_WAVES)
+        sp_hist[q] = 0;
+    __syncthreads();
+    const uint64_t n_waves = (uint64_t)gridDim.x * SP_WAVES;
+    for (uint64_t g = (uint64_t)blockIdx.x * SP_WAVES + wave; g < n_buckets; g += n_waves) {
+        const uint64_t s0 = off[g], n = off[g + 1] - s0;
+        for (uint64_t i = lane; i < n; i += 64)
+            atomicAdd(&cnt[keys[s0 + i]], 1u);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); // LDS operations of one wave complete in order
+        for (uint64_t i = lane; i < n; i += 64) {
+            const uint32_t c = atomicExch(&cnt[keys[s0 + i]], 0u);
+            if (c)
+                atomicAdd(&sp_hist[c > 255u ? 255u : c], 1ull);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+    __syncthreads();
+    for (uint32_t q = threadIdx.x; q < 256; q += 64 * SP_WAVES)
+        if (sp_hist[q])
+            atomicAdd(&hist[q], sp_hist[q]);
+}
+
 // concatenates, per level-1 bucket, the segments of every batch (only needed for > 1 batch)
 __global__ __launch_bounds__(256) void merge_segments_kernel(const uint32_t *__restrict__ src,
                                                              const uint64_t *__restrict__ src_off,
@@ -1206,7 +1242,9 @@ static int run_level(PartState *st, int l, const uint32_t *keys_in, const uint64
     return BRX_OK;
 }
 
-int part_finish_into(brx_counter *c, uint32_t abundance, hipStream_t s, brx_set *dst)
+// d_hist != nullptr: no set is produced (dst is not touched); the keys go through every level and the final buckets
+// are binned into the 256-entry count spectrum (bins 1..255)
+static int part_finish_impl(brx_counter *c, uint32_t abundance, hipStream_t s, brx_set *dst, unsigned long long *d_hist)
 {
     PartState *st = c->part;
     const Plan &pl = st->pl;
@@ -1218,6 +1256,8 @@ int part_finish_into(brx_counter *c, uint32_t abundance, hipStream_t s, brx_set 
     const uint32_t *keys1 = nullptr;
     const uint64_t *l1off = nullptr;
     if (st->batches.empty() || total == 0) {
+        if (d_hist)
+            return BRX_OK; // nothing counted: bins 1..255 stay 0
         if (dst->sparse) {
             if (!dst->d_keylist_n)
                 BRX_HIP(hipMalloc((void **)&dst->d_keylist_n, 8));
@@ -1258,7 +1298,7 @@ int part_finish_into(brx_counter *c, uint32_t abundance, hipStream_t s, brx_set 
     // solid-key list for the probe index: a solid hash was seen more than `abundance` times, so there are at
     // most total / (abundance + 1) of them; real data is far below that, and a list that turns out too short
     // is simply not used (the index is then built from the bit vector)
-    const bool emit = dst->sparse || index_wanted(c->k);
+    const bool emit = !d_hist && (dst->sparse || index_wanted(c->k));
     // lazy bit vector: when the solid hashes are listed anyway, the 2^(2k-4)-byte vector (16 GiB of slices at k = 19)
     // is written only if somebody asks for it later (ensure_bits); BRX_LAZY_BITS=0 writes it here as before
     static const bool lazy_on = [] { const char *e = getenv("BRX_LAZY_BITS"); return !(e && *e == '0'); }();
@@ -1299,7 +1339,7 @@ int part_finish_into(brx_counter *c, uint32_t abundance, hipStream_t s, brx_set 
     static const bool hf_on = [] { const char *e = getenv("BRX_HASH_FINAL"); return !(e && *e == '0'); }();
     const int R_hf = pl.rem_in[pl.nlev - 1];
     const uint64_t nb_hf = pl.nlev >= 2 ? pl.nchild[pl.nlev - 2] : 0;
-    const bool hash_final = hf_on && (dst->sparse || lazy) && pl.nlev >= 3 && R_hf <= 20 && total / nb_hf <= 16384;
+    const bool hash_final = !d_hist && hf_on && (dst->sparse || lazy) && pl.nlev >= 3 && R_hf <= 20 && total / nb_hf <= 16384;
     for (int l = 1; l < pl.nlev; l++) {
         if (hash_final && l == pl.nlev - 1)
             break;
@@ -1337,6 +1377,15 @@ int part_finish_into(brx_counter *c, uint32_t abundance, hipStream_t s, brx_set 
         return BRX_OK;
     }
     const uint64_t *fin_off = st->d_coff[pl.nlev - 1];
+    if (d_hist) {
+        KernelTimer t("part_spectrum", s);
+        const uint64_t nb = pl.nchild[pl.nlev - 1];
+        const uint64_t want = (nb + SP_WAVES - 1) / SP_WAVES;
+        final_spectrum_kernel<<<(int)(want < 256ull * 8ull ? want : 256ull * 8ull), 64 * SP_WAVES, 0, s>>>(st->d_keys_fin, fin_off, nb, d_hist);
+        BRX_HIP(hipGetLastError());
+        trace_stage(s, "spectrum");
+        return BRX_OK;
+    }
     {
         KernelTimer t("part_final_count", s);
         const uint64_t nb = pl.nchild[pl.nlev - 1];
@@ -1357,6 +1406,17 @@ int part_finish_into(brx_counter *c, uint32_t abundance, hipStream_t s, brx_set 
     dst->keylist_valid = emit;
     dst->bits_stale = lazy;
     return BRX_OK;
+}
+
+int part_finish_into(brx_counter *c, uint32_t abundance, hipStream_t s, brx_set *dst)
+{
+    return part_finish_impl(c, abundance, s, dst, nullptr);
+}
+
+// bins 1..255 of the count spectrum into d_hist (256 x u64, zeroed by the caller); the counter is left as it was
+int part_spectrum(brx_counter *c, hipStream_t s, unsigned long long *d_hist)
+{
+    return part_finish_impl(c, 255u, s, nullptr, d_hist);
 }
 
 } // namespace brx

@@ -356,6 +356,7 @@ int part_reset(brx_counter *c);
 int part_add_batch(brx_counter *c, const uint8_t *d_bases, const uint64_t *d_offsets, uint32_t n_reads,
                    uint64_t total_bases, hipStream_t s);
 int part_finish_into(brx_counter *c, uint32_t abundance, hipStream_t s, brx_set *dst);
+int part_spectrum(brx_counter *c, hipStream_t s, unsigned long long *d_hist);
 int part_l1_view(brx_counter *c, void **d_keys, void **d_l1off, uint32_t *n_buckets, uint64_t *n_keys);
 int part_add_partitioned(brx_counter *c, const uint32_t *d_keys, const uint64_t *d_l1off, uint64_t n_keys);
 // used by the correction chain and the host-pointer entry points
@@ -834,16 +835,33 @@ int brx_counter_spectrum(brx_counter_t *c, uint64_t *hist256, void *stream)
 {
     if (!c || !hist256)
         return BRX_ERR_ARG;
-    if (c->strategy != BRX_COUNT_DENSE) {
-        set_error("spectrum needs the dense count strategy");
-        return BRX_ERR_UNSUPPORTED;
-    }
     BRX_TRY(use_device(c->device));
     hipStream_t s = (hipStream_t)stream;
     unsigned long long *d_h = nullptr;
     BRX_HIP(hipMalloc((void **)&d_h, 256 * 8));
     hipError_t e = hipMemsetAsync(d_h, 0, 256 * 8, s);
     const uint64_t nbytes = set_nbits(c->k); // real entries (the table may be padded to 32 B)
+    if (c->strategy == BRX_COUNT_SORTED) {
+        // no table to read: the partitioned keys are counted bucket by bucket (bins 1..255); bin 0 is the rest
+        int st = e == hipSuccess ? part_spectrum(c, s, d_h) : BRX_ERR_HIP;
+        if (st == BRX_OK) {
+            e = hipMemcpyAsync(hist256, d_h, 256 * 8, hipMemcpyDeviceToHost, s);
+            if (e == hipSuccess)
+                e = hipStreamSynchronize(s);
+            if (e != hipSuccess) {
+                set_error("spectrum: %s", hipGetErrorString(e));
+                st = BRX_ERR_HIP;
+            }
+        }
+        (void)hipFree(d_h);
+        if (st != BRX_OK)
+            return st;
+        uint64_t seen = 0;
+        for (int i = 1; i < 256; i++)
+            seen += hist256[i];
+        hist256[0] = nbytes - seen;
+        return BRX_OK;
+    }
     if (e == hipSuccess) {
         KernelTimer t("spectrum", s);
         // padded tail (k <= 2) would add zeros: count whole words of real entries only

@@ -265,7 +265,8 @@ class Counter:
         return p.value, n.value
 
     def spectrum(self, stream: Optional[int] = None) -> np.ndarray:
-        """pcon::spectrum::Spectrum::from_count: uint64[256] histogram of the counts (dense strategy)."""
+        """pcon::spectrum::Spectrum::from_count: uint64[256] histogram of the counts (255 = 255 or more).
+        Either strategy; the counter is left as it was, so `finish(threshold)` can follow."""
         h = np.zeros(256, dtype=np.uint64)
         _lib.check(_lib.lib().brx_counter_spectrum(self._h, h.ctypes.data_as(C.POINTER(C.c_uint64)), stream))
         return h

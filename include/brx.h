@@ -166,8 +166,9 @@ int brx_set_count_finish(brx_counter_t *c, uint8_t abundance, void *stream, brx_
 int brx_set_count_finish_into(brx_counter_t *c, uint8_t abundance, void *stream, brx_set_t *dst);
 /* forget everything counted so far (Counter::new without re-allocating; async on `stream`)   */
 int brx_counter_reset(brx_counter_t *c, void *stream);
-/* dense strategy only: 256-bin histogram of the counts = pcon::spectrum::Spectrum::from_count
- * (src/main.rs:93); hist256[v] = number of canonical k-mers seen exactly v times (255 = 255 or more) */
+/* 256-bin histogram of the counts = pcon::spectrum::Spectrum::from_count (src/main.rs:93):
+ * hist256[v] = number of canonical k-mers seen exactly v times (255 = 255 or more, 0 = never).  Either
+ * strategy; the counter is left as it was, so brx_set_count_finish with the chosen threshold follows.   */
 int brx_counter_spectrum(brx_counter_t *c, uint64_t *hist256, void *stream);
 /* dense strategy only: device view of the u8 table, for the RCCL reduction of SURVEY 8(e)   */
 int brx_counter_device_counts(brx_counter_t *c, void **d_counts, uint64_t *n_bytes);

@@ -113,4 +113,27 @@ def test_cli_surface_matches_reference():
     # spectrum of raw.fasta at k=11: first rise at index 6 -> 7
     assert cli.first_minimum([1436018, 442564, 95498, 19526, 4458, 1221, 460, 494, 100]) == 6
     assert cli.first_minimum([5, 4, 3]) is None
+    a = p.parse_args(["fasta", "-i", "r.fa", "-k", "11", "percent-most", "0.25"])
+    assert a.abundance_selection == "percent-most" and a.percent == 0.25
     assert cli.METHOD_NAMES == ["one", "two", "graph", "greedy", "gap-size"]   # default order, src/cli.rs:121-131
+
+
+def test_abundance_threshold_methods():
+    """br_amd.spectrum (pcon::spectrum::ThresholdMethod, unpinned restatement) on a spectrum worked by hand:
+    index*value = 0,50,40,15,40,150,48,14; running sums 0,50,90,105,145,295,343,357"""
+    from br_amd import spectrum as sp
+    S = [100, 50, 20, 5, 10, 30, 8, 2]
+    assert sp.first_minimum(S) == 3                      # 10 > 5
+    assert sp.rarefaction(S, 0.1) == 3                   # 5/105 < 0.1 (100/0 = inf, 50/50, 20/90 are not)
+    assert sp.rarefaction(S, 0.001) is None
+    assert sp.percent_at_least(S, 0.3) == 4              # 145/357 = 0.406 is the first ratio > 0.3
+    assert sp.percent_at_most(S, 0.3) == 3
+    assert sp.percent_at_least(S, 1.0) is None
+    assert sp.get_threshold(S, "percent-least", 0.3) == 4 and sp.get_threshold(S, "percent-most", 0.3) == 3
+    assert sp.get_threshold(S, "rarefaction", 0.1) == 3 and sp.get_threshold(S, "first-minimum") == 3
+    Z = [0] * 256                                        # nothing counted: 0/0 ratios compare false
+    assert sp.first_minimum(Z) is None and sp.rarefaction(Z, 0.5) is None and sp.percent_at_least(Z, 0.5) is None
+    assert sp.percent_at_most(Z, 0.5) is None
+    import pytest
+    with pytest.raises(ValueError):
+        sp.get_threshold(S, "median")

@@ -512,10 +512,51 @@ def test_cli_reference_integration_commands(tmp_path, golden_dir, raw_reads, sol
         assert seq == O.correct_record(om, r, False)
 
 
-def test_spectrum_matches_oracle(raw_reads):
-    cnt = br_amd.Counter(11, 0, _lib.COUNT_DENSE)
+@pytest.mark.parametrize("strategy", [_lib.COUNT_DENSE, _lib.COUNT_SORTED])
+def test_spectrum_matches_oracle(raw_reads, strategy):
+    cnt = br_amd.Counter(11, 0, strategy)
     cnt.add_reads(raw_reads)
     spec = cnt.spectrum()
     exp = np.bincount(O.count_reads(11, raw_reads), minlength=256)
     assert np.array_equal(spec.astype(np.int64), exp.astype(np.int64))
+    # the spectrum leaves the counter as it was: the set of the chosen threshold follows from the same counts
+    s = cnt.finish(2)
+    assert s.to_solid_bytes() == O.Solid.from_count(11, O.count_reads(11, raw_reads), 2).to_bytes()
+
+
+@pytest.mark.parametrize("k", [13, 15, 17])
+def test_spectrum_sorted_saturation_and_batches(k):
+    """sorted-strategy spectrum over several batches, with hashes seen more than 255 times (bin 255 = 255 or more)"""
+    rng = np.random.default_rng(500 + k)
+    genome = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), 3000).tobytes()
+    reads = [genome[i:i + 400] for i in rng.integers(0, 2600, 3000)]            # ~400x coverage: counts beyond 255
+    reads += [rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), 300).tobytes() for _ in range(200)]
+    reads += [b"", b"ACG", genome[:k], genome[:k - 1]]
+    cnt = br_amd.Counter(k, 0, _lib.COUNT_SORTED)
+    for lo in range(0, len(reads), 700):
+        cnt.add_reads(reads[lo:lo + 700])
+    spec = cnt.spectrum().astype(np.int64)
+    exp = np.bincount(O.count_reads(k, reads), minlength=256).astype(np.int64)
+    assert exp[255] > 0
+    assert np.array_equal(spec, exp)
+    assert int(spec.sum()) == 1 << (2 * k - 1)
+
+
+def test_cli_abundance_methods(tmp_path, golden_dir, raw_reads):
+    """`br ... fasta -k 11 rarefaction|percent-most|percent-least P` (src/main.rs:98-107): threshold from the GPU
+    spectrum through br_amd.spectrum (pcon's formulas, unpinned), then the same set and corrections as `-a thr`"""
+    from br_amd import cli, fasta, spectrum
+    raw = os.path.join(golden_dir, "raw.fasta")
+    counts = O.count_reads(11, raw_reads)
+    spec = np.bincount(counts, minlength=256)
+    for method, pct in (("rarefaction", "0.001"), ("percent-least", "0.2"), ("percent-most", "0.2")):
+        thr = spectrum.get_threshold(spec, method, float(pct))
+        assert thr is not None and 0 < thr < 255
+        out = str(tmp_path / f"corr_{method}.fasta")
+        assert cli.main(["-i", raw, "-o", out, "-c", "one", "fasta", "-i", raw, "-k", "11", method, pct]) == 0
+        om = O.build_methods(O.Solid.from_count(11, counts, thr), ["one"], 5, 7)
+        got = list(fasta.read_records(open(out, "rb")))
+        assert len(got) == 206
+        for (_, _, seq), r in zip(got[:25], raw_reads[:25]):
+            assert seq == O.correct_record(om, r, False)
     assert spec[:8].tolist() == [1436018, 442564, 95498, 19526, 4458, 1221, 460, 494]   # SURVEY 8(f) N2
