@@ -27,7 +27,19 @@ namespace {
 
 constexpr size_t LINE_BASES = 80;          // noodles fasta::Writer default line_base_count
 constexpr size_t READ_CHUNK = 8u << 20;    // bytes per read() call
-constexpr uint64_t BATCH_BASES = 128ull << 20;
+// bases per batch.  Measured on 1 Gbp of 10 kb reads (tools/pipe_sweep.sh): 16-32 MB batches run the whole
+// FASTA -> FASTA job 1.7x faster than 128 MB ones -- the kernels lose a little on 3 000-read batches, but the
+// pinned and device buffers (allocated and first touched once per slot) are a quarter of the size and the writer
+// starts after 5 ms of parsing instead of 30; below 16 MB the per-batch overheads take over.
+inline uint64_t batch_bases()
+{
+    static const uint64_t v = [] {
+        const char *e = getenv("BRX_PIPE_BATCH_MB");
+        const long mb = e ? atol(e) : 0;
+        return (uint64_t)(mb >= 1 && mb <= 4096 ? mb : 32) << 20;
+    }();
+    return v;
+}
 constexpr int N_SLOTS = 5;
 
 inline bool is_ws(unsigned char c) { return c == ' ' || c == '\t' || c == '\n' || c == '\r' || c == '\v' || c == '\f'; }
@@ -35,6 +47,13 @@ inline bool is_ws(unsigned char c) { return c == ' ' || c == '\t' || c == '\n' |
 double now_s()
 {
     return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// BRX_PIPE_TRACE=1: per-allocation and per-batch timings on stderr
+inline bool pipe_trace()
+{
+    static const bool on = [] { const char *e = getenv("BRX_PIPE_TRACE"); return e && *e == '1'; }();
+    return on;
 }
 
 // growable pinned host buffer (hipHostMalloc: H2D / D2H at link speed, async capable)
@@ -49,7 +68,10 @@ struct Pinned {
         while (want < need)
             want += want / 2 + (1u << 20);
         uint8_t *q = nullptr;
+        const double t0 = now_s();
         hipError_t e = hipHostMalloc((void **)&q, want, hipHostMallocDefault);
+        if (pipe_trace())
+            fprintf(stderr, "[brx pipe] hipHostMalloc %.1f MB: %.2f ms\n", (double)want / 1e6, (now_s() - t0) * 1e3);
         if (e != hipSuccess) {
             set_error("hipHostMalloc(%llu B): %s", (unsigned long long)want, hipGetErrorString(e));
             return BRX_ERR_NOMEM;
@@ -70,6 +92,28 @@ struct Pinned {
     }
 };
 
+// growable byte buffer without value-initialisation (a std::vector resize would zero 140 MB per batch first)
+struct RawBuf {
+    char *p = nullptr;
+    size_t cap = 0, len = 0;
+    bool reserve(size_t need)
+    {
+        if (need <= cap)
+            return true;
+        free(p);
+        cap = 0;
+        p = (char *)malloc(need + need / 8);
+        if (!p)
+            return false;
+        cap = need + need / 8;
+        return true;
+    }
+    RawBuf() = default;
+    RawBuf(const RawBuf &) = delete;
+    RawBuf &operator=(const RawBuf &) = delete;
+    ~RawBuf() { free(p); }
+};
+
 struct Batch {
     uint64_t seq = 0;             // position in the stream (the writer emits in this order)
     Pinned bases;                 // concatenated sequences
@@ -79,6 +123,7 @@ struct Batch {
     uint64_t total = 0;
     Pinned out;                   // corrected bases
     std::vector<uint64_t> out_offsets;
+    RawBuf text;                  // the batch as FASTA text (filled by the GPU worker that corrected it)
     bool last = false;
     void clear()
     {
@@ -200,6 +245,7 @@ class FastaBatcher {
             b.last = true;
             return BRX_OK;
         }
+        const uint64_t target = batch_bases();
         for (;;) {
             if (have_def_) { // definition read while closing the previous record
                 if (!open_record(b))
@@ -220,7 +266,7 @@ class FastaBatcher {
                     break;
                 }
                 have_def_ = true;
-                if (b.n() >= max_records_ || b.total >= BATCH_BASES)
+                if (b.n() >= max_records_ || b.total >= target)
                     break; // batch full: the pending definition opens the next one
                 continue;
             }
@@ -228,9 +274,10 @@ class FastaBatcher {
                 done_ = true;
                 break;
             }
-            if (b.total + len + 64 > b.bases.cap) // one allocation per slot in the common case: a full batch + one long read
-                BRX_TRY(b.bases.reserve(b.total + len + 64 > BATCH_BASES + (32ull << 20) ? b.total + len + 64 : BATCH_BASES + (32ull << 20),
-                                        b.total));
+            if (b.total + len + 64 > b.bases.cap) { // one allocation per slot in the common case: the batch + one long read
+                const uint64_t room = target + target / 4 + (1ull << 20);
+                BRX_TRY(b.bases.reserve(b.total + len + 64 > room ? b.total + len + 64 : room, b.total));
+            }
             memcpy(b.bases.p + b.total, line, len);
             b.total += len;
         }
@@ -372,10 +419,16 @@ int correct_one_batch(brx_chain_t *chain, DevBufs &dv, hipStream_t s, Batch &b)
     b.out_offsets.assign((size_t)n + 1, 0);
     if (n == 0)
         return BRX_OK;
+    const bool tr = pipe_trace();
+    const double t0 = now_s();
     BRX_TRY(dv.ensure(b.total, n));
+    const double t1 = now_s();
     if (b.total)
         BRX_HIP(hipMemcpyAsync(dv.d_in, b.bases.p, b.total, hipMemcpyHostToDevice, s));
     BRX_HIP(hipMemcpyAsync(dv.d_off, b.offsets.data(), ((size_t)n + 1) * 8, hipMemcpyHostToDevice, s));
+    if (tr)
+        BRX_HIP(hipStreamSynchronize(s));
+    const double t2 = now_s();
     uint64_t out_total = 0;
     int st = brx_chain_correct_batch_device(chain, dv.d_in, dv.d_off, n, b.total, dv.d_out, dv.out_cap, dv.d_out_off,
                                             &out_total, s);
@@ -388,15 +441,21 @@ int correct_one_batch(brx_chain_t *chain, DevBufs &dv, hipStream_t s, Batch &b)
                                             &out_total, s);
     }
     BRX_TRY(st);
+    const double t3 = now_s();
     BRX_TRY(b.out.reserve(out_total + 64, 0));
+    const double t4 = now_s();
     if (out_total)
         BRX_HIP(hipMemcpyAsync(b.out.p, dv.d_out, out_total, hipMemcpyDeviceToHost, s));
     BRX_HIP(hipMemcpyAsync(b.out_offsets.data(), dv.d_out_off, ((size_t)n + 1) * 8, hipMemcpyDeviceToHost, s));
     BRX_HIP(hipStreamSynchronize(s));
+    if (tr)
+        fprintf(stderr, "[brx pipe] batch %llu (%u records, %.1f MB): dev alloc %.2f, h2d %.2f, correct %.2f, pinned out %.2f, d2h %.2f ms\n",
+                (unsigned long long)b.seq, n, (double)b.total / 1e6, (t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3, (t4 - t3) * 1e3,
+                (now_s() - t4) * 1e3);
     return BRX_OK;
 }
 
-void format_batch(const Batch &b, std::vector<char> &o)
+int format_batch(const Batch &b, RawBuf &o)
 {
     const uint32_t n = b.n();
     const uint64_t out_total = n ? b.out_offsets[n] : 0;
@@ -406,8 +465,11 @@ void format_batch(const Batch &b, std::vector<char> &o)
         const uint64_t len = b.out_offsets[r + 1] - b.out_offsets[r];
         need += (len + LINE_BASES - 1) / LINE_BASES;
     }
-    o.resize(need);
-    char *w = o.data();
+    if (!o.reserve(need)) {
+        set_error("out of host memory formatting a batch (%llu B)", (unsigned long long)need);
+        return BRX_ERR_NOMEM;
+    }
+    char *w = o.p;
     uint32_t dprev = 0;
     for (uint32_t r = 0; r < n; r++) {
         *w++ = '>';
@@ -431,7 +493,8 @@ void format_batch(const Batch &b, std::vector<char> &o)
             *w++ = '\n';
         }
     }
-    o.resize((size_t)(w - o.data()));
+    o.len = (size_t)(w - o.p);
+    return BRX_OK;
 }
 
 // shared by brx_count_fasta_fd / brx_set_insert_fasta_fd: parse on a thread, hand every batch (already on the
@@ -568,6 +631,9 @@ int brx_run_correction_fd(const brx_set_t *set, const brx_method_t *methods, uin
                 break;
             }
             b->seq = seq++;
+            if (pipe_trace())
+                fprintf(stderr, "[brx pipe] t=%.1f ms: batch %llu parsed (%.1f ms)\n", (now_s() - t_start) * 1e3,
+                        (unsigned long long)b->seq, (now_s() - t0) * 1e3);
             const bool last = b->last;
             q_ready.push(b);
             if (last)
@@ -594,9 +660,14 @@ int brx_run_correction_fd(const brx_set_t *set, const brx_method_t *methods, uin
             if (!sh.failed()) {
                 const double t0 = now_s();
                 st = correct_one_batch(chain, dv, s, *b);
+                if (st == BRX_OK) // the 80-column text too: this thread would otherwise only wait for the next batch
+                    st = format_batch(*b, b->text);
                 const double dt = now_s() - t0;
                 if (st != BRX_OK)
                     sh.fail(st);
+                if (pipe_trace())
+                    fprintf(stderr, "[brx pipe] t=%.1f ms: batch %llu corrected + formatted (%.1f ms)\n", (now_s() - t_start) * 1e3,
+                            (unsigned long long)b->seq, dt * 1e3);
                 std::lock_guard<std::mutex> g(done_mu);
                 t_gpu += dt;
             }
@@ -611,10 +682,17 @@ int brx_run_correction_fd(const brx_set_t *set, const brx_method_t *methods, uin
         if (s)
             (void)hipStreamDestroy(s);
     };
-    std::thread gpu_a(gpu_worker), gpu_b(gpu_worker);
+    // two workers keep H2D, kernels, D2H and formatting of consecutive batches overlapped (BRX_PIPE_WORKERS: 1..3)
+    static const int n_workers = [] {
+        const char *e = getenv("BRX_PIPE_WORKERS");
+        const int v = e ? atoi(e) : 2;
+        return v < 1 ? 1 : (v > 3 ? 3 : v);
+    }();
+    std::vector<std::thread> gpu_threads;
+    for (int i = 0; i < n_workers; i++)
+        gpu_threads.emplace_back(gpu_worker);
 
     std::thread writer([&] {
-        std::vector<char> obuf;
         uint64_t next = 0;
         for (;;) {
             Batch *b = nullptr;
@@ -638,9 +716,11 @@ int brx_run_correction_fd(const brx_set_t *set, const brx_method_t *methods, uin
             next++;
             if (!sh.failed()) {
                 const double t0 = now_s();
-                format_batch(*b, obuf);
-                int st = write_all(out_fd, obuf.data(), obuf.size());
+                int st = write_all(out_fd, b->text.p, b->text.len);
                 t_write += now_s() - t0;
+                if (pipe_trace())
+                    fprintf(stderr, "[brx pipe] t=%.1f ms: batch %llu written (%.1f ms)\n", (now_s() - t_start) * 1e3,
+                            (unsigned long long)b->seq, (now_s() - t0) * 1e3);
                 if (st != BRX_OK)
                     sh.fail(st);
                 n_records += b->n();
@@ -653,8 +733,8 @@ int brx_run_correction_fd(const brx_set_t *set, const brx_method_t *methods, uin
     });
 
     reader.join();
-    gpu_a.join();
-    gpu_b.join();
+    for (auto &t : gpu_threads)
+        t.join();
     {
         std::lock_guard<std::mutex> g(done_mu);
         gpu_finished = true;
