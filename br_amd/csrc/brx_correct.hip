@@ -354,8 +354,9 @@ __device__ __forceinline__ uint32_t scen_width(uint32_t sub, uint32_t c, int G, 
 
 template <int G, int M>
 // One fits 80 VGPRs without spilling: 6 waves per SIMD instead of 5 (the kernel waits on memory 60 % of the
-// time, measured 8 % faster); the other methods keep the compiler's own choice
-__global__ __launch_bounds__(256, (M == BRX_ONE ? 6 : (M == BRX_GAP_SIZE ? 5 : 1))) void correct_kernel(PassParams p)
+// time, measured 8 % faster), and its 64-lane form (no group shuffles to keep) fits 72: 7 waves; the other methods
+// keep the compiler's own choice
+__global__ __launch_bounds__(256, (M == BRX_ONE ? (G == 64 ? 7 : 6) : (M == BRX_GAP_SIZE ? 5 : 1))) void correct_kernel(PassParams p)
 {
     constexpr bool HAS_ERRLEN = (M == BRX_GRAPH || M == BRX_GAP_SIZE);
     constexpr bool HAS_ONE = (M == BRX_ONE || M == BRX_GAP_SIZE);
