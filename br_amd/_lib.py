@@ -77,6 +77,7 @@ SIGNATURES = {
     "brx_set_count_finish_into": (C.c_int, [_vp, C.c_uint8, _vp, _vp]),
     "brx_counter_reset": (C.c_int, [_vp, _vp]),
     "brx_counter_spectrum": (C.c_int, [_vp, _u64p, _vp]),
+    "brx_counter_load_counts": (C.c_int, [_vp, C.c_uint64, C.c_char_p, C.c_uint64]),
     "brx_counter_device_counts": (C.c_int, [_vp, _pp, _u64p]),
     "brx_counter_clamp": (C.c_int, [_vp, C.c_uint8, _vp]),
     "brx_counter_l1_view": (C.c_int, [_vp, _pp, _pp, C.POINTER(C.c_uint32), _u64p]),

@@ -3,13 +3,15 @@
     python -m br_amd -i reads.fa -o corr.fa [-s] [-c one -c graph ...] [-C 5] [-M 7] \
         fasta -i reads.fa -k 19 -a 3                       # count -> threshold -> correct (src/main.rs:72-85)
         solid -i set.solid -f solid                        # load a pcon .solid set     (src/main.rs:117-120)
+        count -i table.pcon -a 3                           # load a pcon count table    (src/main.rs:59-70)
         solid -i reads.fa -f fasta -k 19                   # presence-only set          (src/set/pcon.rs:47-112)
 
 Same flags, defaults and quirks as the reference: `-s/--two-side` DISABLES the reverse pass
 (src/lib.rs:48,110); `fasta -k` is forced odd (src/cli.rs:277-279); without `-a` an abundance method
 sub-command is needed (src/main.rs:95-110): `first-minimum`, `rarefaction P`, `percent-most P`, `percent-least P`
 pick the threshold from the count spectrum (br_amd/spectrum.py: pcon's published formulas, unpinned by the
-reference's tests).  The `count` sub-command (pcon count files, row N3 of SURVEY 8(f)) fails loudly here; `large-kmer -f fasta` (N4) builds a sparse set for odd k <= 31.  `-t` (rayon
+reference's tests).  `count -i table` loads a pcon count table ([k][2^(2k-1) u8 counters], layout unpinned: the
+reference holds no such fixture) and thresholds it the same way; `large-kmer -f fasta` (N4) builds a sparse set for odd k <= 31.  `-t` (rayon
 pool size) is accepted and ignored: the GPU is the pool.
 """
 from __future__ import annotations
@@ -104,28 +106,31 @@ def _records(paths: List[str]):
                 yield seq
 
 
+def threshold_and_finish(cnt: Counter, args) -> Pcon:
+    """count2solid, src/main.rs:86-115: `-a N` wins; otherwise the counts are histogrammed on the GPU (no u8 table
+    for the partitioned counter: its keys are binned bucket by bucket), the threshold is picked on the host and the
+    same counter is finished with it"""
+    if args.abundance is not None:
+        return cnt.finish(args.abundance)
+    if args.abundance_selection is None:
+        raise SystemExit("Error: You must provide an abundance method or an abundance threshold")      # main.rs:109
+    thr = spectrum.get_threshold(cnt.spectrum(), args.abundance_selection, getattr(args, "percent", 0.0))
+    if thr is None:
+        raise SystemExit("Error: Can't compute minimal abundance")                  # error.rs ComputeAbundanceThreshold
+    return cnt.finish(thr)
+
+
 def build_set(args) -> Pcon:
     dev = args.device
     if args.subcommand == "fasta":
         k = fasta_kmer_size(args.kmer_size)
-        if args.abundance is not None:
-            cnt = Counter(k, dev)
-            for path in args.sub_inputs:
-                with open_input(path) as f:
-                    cnt.count_fasta(f)
-            return cnt.finish(args.abundance)
-        if args.abundance_selection is None:
+        if args.abundance is None and args.abundance_selection is None:
             raise SystemExit("Error: You must provide an abundance method or an abundance threshold")  # main.rs:109
-        # count once, histogram the counts on the GPU (no u8 table: the partitioned keys are binned bucket by
-        # bucket), pick the threshold on the host, then finish the same counter with it (src/main.rs:93-114)
         cnt = Counter(k, dev)
         for path in args.sub_inputs:
             with open_input(path) as f:
                 cnt.count_fasta(f)
-        thr = spectrum.get_threshold(cnt.spectrum(), args.abundance_selection, getattr(args, "percent", 0.0))
-        if thr is None:
-            raise SystemExit("Error: Can't compute minimal abundance")              # error.rs ComputeAbundanceThreshold
-        return cnt.finish(thr)
+        return threshold_and_finish(cnt, args)
     if args.subcommand == "solid":
         if args.format == "solid":
             with open_input(args.sub_input) as f:
@@ -135,7 +140,10 @@ def build_set(args) -> Pcon:
         with open_input(args.sub_input) as f:
             return Pcon.from_fasta_file(f, args.kmer_size, dev)
     if args.subcommand == "count":
-        raise SystemExit("the pcon count-file format is not implemented on the HIP path (unpinned, SURVEY 8(f) N3)")
+        # src/main.rs:59-70: Counter::from_stream, then the same threshold -> Solid::from_count as `fasta`
+        with open_input(args.sub_inputs) as f:
+            cnt = Counter.from_count_stream(f, dev)
+        return threshold_and_finish(cnt, args)
     # large-kmer -f fasta: set::Hash::from_fasta (src/set/hash.rs:40-60, src/main.rs:147-163) = every canonical k-mer of
     # every record, no counting.  Same membership as a presence-only Pcon; for k >= 21 the set is sparse (a chained
     # hash table in HBM instead of the bit vector).  Odd k only: cocktail's parity-canonical form is not a function

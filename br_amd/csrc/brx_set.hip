@@ -893,6 +893,26 @@ int brx_counter_device_counts(brx_counter_t *c, void **d_counts, uint64_t *n_byt
     return BRX_OK;
 }
 
+int brx_counter_load_counts(brx_counter_t *c, uint64_t first, const uint8_t *counts, uint64_t n)
+{
+    if (!c || (!counts && n))
+        return BRX_ERR_ARG;
+    if (c->strategy != BRX_COUNT_DENSE) {
+        set_error("load_counts needs the dense count strategy");
+        return BRX_ERR_UNSUPPORTED;
+    }
+    const uint64_t entries = set_nbits(c->k);
+    if (first > entries || n > entries - first) {
+        set_error("load_counts: [%llu, +%llu) is outside the %llu counters of k=%d", (unsigned long long)first,
+                  (unsigned long long)n, (unsigned long long)entries, c->k);
+        return BRX_ERR_ARG;
+    }
+    BRX_TRY(use_device(c->device));
+    if (n)
+        BRX_HIP(hipMemcpy((uint8_t *)c->d_counts + first, counts, n, hipMemcpyHostToDevice));
+    return BRX_OK;
+}
+
 int brx_counter_clamp(brx_counter_t *c, uint8_t cap, void *stream)
 {
     if (!c || c->strategy != BRX_COUNT_DENSE)

@@ -264,6 +264,32 @@ class Counter:
         _lib.check(_lib.lib().brx_counter_device_counts(self._h, C.byref(p), C.byref(n)))
         return p.value, n.value
 
+    def load_counts(self, first: int, counts: bytes) -> None:
+        """overwrite counters [first, first + len(counts)) of a dense counter (`br count`: a table counted elsewhere)"""
+        _lib.check(_lib.lib().brx_counter_load_counts(self._h, first, bytes(counts), len(counts)))
+
+    @classmethod
+    def from_count_stream(cls, f, device: int = 0, chunk: int = 64 << 20) -> "Counter":
+        """pcon::counter::Counter::<u8>::from_stream (src/main.rs:59-61): a count table written by `pcon count`.
+        Layout as restated from pcon's published serializer -- one byte k, then the 2^(2k-1) u8 counters of the
+        canonical hashes in order (the reference builds pcon with `count_u8`, Cargo.toml:23); the reference holds no
+        count-file fixture, so the layout is UNPINNED.  A short stream is an error, like read_exact's."""
+        head = f.read(1)
+        if len(head) != 1:
+            raise _lib.BrxError(-5, "count stream: empty")
+        k = head[0]
+        if not 1 <= k <= 19:
+            raise _lib.BrxError(-1, f"count stream: k={k} (a dense u8 table fits one GPU for k <= 19)")
+        cnt = cls(k, device, _lib.COUNT_DENSE)
+        total, pos = 1 << (2 * k - 1), 0
+        while pos < total:
+            buf = f.read(min(chunk, total - pos))
+            if not buf:
+                raise _lib.BrxError(-5, f"count stream: ends after {pos} of {total} counters")
+            cnt.load_counts(pos, buf)
+            pos += len(buf)
+        return cnt
+
     def spectrum(self, stream: Optional[int] = None) -> np.ndarray:
         """pcon::spectrum::Spectrum::from_count: uint64[256] histogram of the counts (255 = 255 or more).
         Either strategy; the counter is left as it was, so `finish(threshold)` can follow."""

@@ -172,6 +172,9 @@ int brx_counter_reset(brx_counter_t *c, void *stream);
 int brx_counter_spectrum(brx_counter_t *c, uint64_t *hist256, void *stream);
 /* dense strategy only: device view of the u8 table, for the RCCL reduction of SURVEY 8(e)   */
 int brx_counter_device_counts(brx_counter_t *c, void **d_counts, uint64_t *n_bytes);
+/* dense strategy only: overwrite counters [first, first + n) with counts computed elsewhere -- `br count`
+ * (src/main.rs:59-70: pcon::counter::Counter::from_stream) hands a whole table over this way        */
+int brx_counter_load_counts(brx_counter_t *c, uint64_t first, const uint8_t *counts, uint64_t n);
 /* clamp every count to min(count, cap) in place (the exact-sum trick before an u8 all-reduce) */
 int brx_counter_clamp(brx_counter_t *c, uint8_t cap, void *stream);
 /* partitioned strategy, multi-GPU exchange (done on keys instead of the count vector):

@@ -560,3 +560,37 @@ def test_cli_abundance_methods(tmp_path, golden_dir, raw_reads):
         for (_, _, seq), r in zip(got[:25], raw_reads[:25]):
             assert seq == O.correct_record(om, r, False)
     assert spec[:8].tolist() == [1436018, 442564, 95498, 19526, 4458, 1221, 460, 494]
+
+
+def test_cli_count_subcommand(tmp_path, golden_dir, raw_reads, solid_fixture_bytes):
+    """`br ... count -i table -a 2` (src/main.rs:59-70): a count table ([k][u8 counters], layout unpinned) thresholded
+    like `fasta` -- from the oracle's counts of raw.fasta at k = 11 it must give the reference's own .solid fixture"""
+    import gzip
+    from br_amd import cli, fasta
+    raw = os.path.join(golden_dir, "raw.fasta")
+    counts = O.count_reads(11, raw_reads)
+    table = str(tmp_path / "raw.k11.pcon")
+    with open(table, "wb") as f:
+        f.write(bytes([11]) + counts.tobytes())
+    with open(table, "rb") as f:
+        cnt = br_amd.Counter.from_count_stream(f, 0, chunk=100000)
+    assert np.array_equal(cnt.spectrum().astype(np.int64), np.bincount(counts, minlength=256).astype(np.int64))
+    assert cnt.finish(2).to_solid_bytes() == solid_fixture_bytes
+    table_gz = table + ".gz"
+    with gzip.open(table_gz, "wb") as f:
+        f.write(bytes([11]) + counts.tobytes())
+    out_c, out_s = str(tmp_path / "c.fasta"), str(tmp_path / "s.fasta")
+    assert cli.main(["-i", raw, "-o", out_c, "-c", "one", "count", "-i", table_gz, "-a", "2"]) == 0
+    assert cli.main(["-i", raw, "-o", out_s, "-c", "one", "solid", "-i", os.path.join(golden_dir, "raw.k11.a2.solid"), "-f", "solid"]) == 0
+    assert open(out_c, "rb").read() == open(out_s, "rb").read()
+    out_m = str(tmp_path / "m.fasta")
+    assert cli.main(["-i", raw, "-o", out_m, "-c", "one", "count", "-i", table, "first-minimum"]) == 0
+    om = O.build_methods(O.Solid.from_count(11, counts, 6), ["one"], 5, 7)
+    got = list(fasta.read_records(open(out_m, "rb")))
+    for (_, _, seq), r in zip(got[:20], raw_reads[:20]):
+        assert seq == O.correct_record(om, r, False)
+    with open(table, "rb") as f:
+        short = f.read(5000)
+    import io
+    with pytest.raises(_lib.BrxError):
+        br_amd.Counter.from_count_stream(io.BytesIO(short), 0)
