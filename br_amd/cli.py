@@ -5,6 +5,7 @@
         solid -i set.solid -f solid                        # load a pcon .solid set     (src/main.rs:117-120)
         count -i table.pcon -a 3                           # load a pcon count table    (src/main.rs:59-70)
         solid -i reads.fa -f fasta -k 19                   # presence-only set          (src/set/pcon.rs:47-112)
+        solid -i reads.fq -f fastq -k 19 | solid -i kmers.csv -f csv -k 19   # the reference's optional features
 
 Same flags, defaults and quirks as the reference: `-s/--two-side` DISABLES the reverse pass
 (src/lib.rs:48,110); `fasta -k` is forced odd (src/cli.rs:277-279); without `-a` an abundance method
@@ -82,11 +83,11 @@ def parser() -> argparse.ArgumentParser:
     abundance_methods(f)
     s = sub.add_parser("solid", help="With Solid")
     s.add_argument("-i", "--input", dest="sub_input", required=True)
-    s.add_argument("-f", "--format", choices=["solid", "fasta"], required=True)
+    s.add_argument("-f", "--format", choices=["solid", "fasta", "fastq", "csv"], required=True)
     s.add_argument("-k", "--kmer-size", type=int, default=None)
     lk = sub.add_parser("large-kmer", help="Large Kmer mode")
     lk.add_argument("-i", "--input", dest="sub_input", required=True)
-    lk.add_argument("-f", "--format", choices=["fasta"], required=True)
+    lk.add_argument("-f", "--format", choices=["fasta", "fastq", "csv"], required=True)
     lk.add_argument("-k", "--kmer-size", type=int, required=True)
     return p
 
@@ -137,8 +138,7 @@ def build_set(args) -> Pcon:
                 return Pcon.from_pcon_solid(f.read(), dev)
         if args.kmer_size is None:
             raise SystemExit("Error: Solid input fasta require kmer size")            # error.rs SolidRequireKmerSize
-        with open_input(args.sub_input) as f:
-            return Pcon.from_fasta_file(f, args.kmer_size, dev)
+        return presence_set(args.sub_input, args.format, args.kmer_size, dev)
     if args.subcommand == "count":
         # src/main.rs:59-70: Counter::from_stream, then the same threshold -> Solid::from_count as `fasta`
         with open_input(args.sub_inputs) as f:
@@ -150,8 +150,21 @@ def build_set(args) -> Pcon:
     # of the {k-mer, revcomp} pair for even k.
     if args.kmer_size % 2 == 0 or not 1 <= args.kmer_size <= 31:
         raise SystemExit("Error: large-kmer mode needs an odd k <= 31 on the HIP path (k=%d)" % args.kmer_size)
-    with open_input(args.sub_input) as f:
-        return Pcon.from_fasta_file(f, args.kmer_size, dev)
+    return presence_set(args.sub_input, args.format, args.kmer_size, dev)
+
+
+def presence_set(path: str, fmt: str, k: int, dev: int) -> Pcon:
+    """Pcon::from_fasta / from_fastq / from_csv and their set::Hash twins: every canonical k-mer of every record
+    (FASTA through the native pipeline; FASTQ and CSV -- optional features of the reference -- parsed on the host)"""
+    with open_input(path) as f:
+        if fmt == "fasta":
+            return Pcon.from_fasta_file(f, k, dev)
+        if fmt == "fastq":
+            return Pcon.from_fasta(fasta.read_fastq_sequences(f), k, dev)
+        try:
+            return Pcon.from_fasta(fasta.read_csv_kmers(f, k), k, dev)
+        except ValueError as e:
+            raise SystemExit(f"Error: {e}")
 
 
 def main(argv: Optional[List[str]] = None) -> int:

@@ -594,3 +594,41 @@ def test_cli_count_subcommand(tmp_path, golden_dir, raw_reads, solid_fixture_byt
     import io
     with pytest.raises(_lib.BrxError):
         br_amd.Counter.from_count_stream(io.BytesIO(short), 0)
+
+
+def test_cli_solid_fastq_and_csv(tmp_path, golden_dir, raw_reads):
+    """`solid -f fastq|csv` / `large-kmer -f fastq` (src/set/pcon.rs:27-45,114-181; optional features of the reference):
+    the same presence-only set as the FASTA form of the same sequences"""
+    from br_amd import cli
+    k = 11
+    reads = raw_reads[:30]
+    fa, fq, cs = (str(tmp_path / n) for n in ("r.fa", "r.fq", "k.csv"))
+    with open(fa, "wb") as f:
+        for i, r in enumerate(reads):
+            f.write(b">r%d\n%s\n" % (i, r))
+    with open(fq, "wb") as f:
+        for i, r in enumerate(reads):
+            f.write(b"@r%d desc\n%s\n+\n%s\n" % (i, r, b"I" * len(r)))
+        f.write(b"@broken\nACGT\n+\nII\n@never\nACGTACGTACGTACGT\n+\nIIIIIIIIIIIIIIII\n")   # stream ends at the bad record
+    kmers = sorted({r[j:j + k] for r in reads[:5] for j in range(len(r) - k + 1)})
+    with open(cs, "wb") as f:
+        f.write(b"kmer,count\n" + b"".join(km + b",1\n" for km in kmers))
+    ref = O.Solid(k)
+    for r in reads:
+        ref.set_seq(r)
+    assert cli.presence_set(fa, "fasta", k, 0).to_solid_bytes() == ref.to_bytes()
+    assert cli.presence_set(fq, "fastq", k, 0).to_solid_bytes() == ref.to_bytes()
+    ref5 = O.Solid(k)
+    for r in reads[:5]:
+        ref5.set_seq(r)
+    assert cli.presence_set(cs, "csv", k, 0).to_solid_bytes() == ref5.to_bytes()
+    with open(cs, "ab") as f:
+        f.write(b"ACGT,1\n")
+    with pytest.raises(SystemExit):
+        cli.presence_set(cs, "csv", k, 0)
+    a = cli.parser().parse_args(["large-kmer", "-i", fq, "-f", "fastq", "-k", "21"])
+    s21 = cli.build_set(a)
+    assert s21.is_sparse()
+    om = O.Solid.sparse_from_count(21, reads, 0)
+    probe = [O.seq2bit(reads[3][j:j + 21]) for j in range(0, 400, 7)] + [O.seq2bit(b"ACGTTGCAACGTTGCAACGTA")]
+    assert [s21.get(x) for x in probe] == [om.get(x) for x in probe]
