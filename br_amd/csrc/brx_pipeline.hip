@@ -20,6 +20,7 @@
 #include <errno.h>
 #include <string.h>
 #include <unistd.h>
+#include <poll.h>
 
 using namespace brx;
 
@@ -174,62 +175,150 @@ class Queue {
     bool closed_ = false;
 };
 
-// ---- FASTA reader: whole lines out of a growing buffer -------------------------------------------
+// ---- FASTA reader: whole lines out of blocks that a read-ahead thread fills ---------------------------
+// read() (a kernel copy of the whole stream) runs on its own thread, READ_CHUNK bytes at a time into a small pool of
+// blocks; next() hands out lines in place -- only a line that straddles two blocks is assembled in `carry_`.
 class LineReader {
   public:
-    explicit LineReader(int fd) : fd_(fd) { buf_.resize(READ_CHUNK * 2); }
-    // next line without its trailing run of \r / \n (python's rstrip(b"\r\n")); false at end of input
+    explicit LineReader(int fd) : fd_(fd)
+    {
+        for (auto &b : pool_)
+            free_.push_back(&b);
+        io_ = std::thread([this] { pump(); });
+    }
+    ~LineReader()
+    {
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        io_.join();
+    }
+    LineReader(const LineReader &) = delete;
+    LineReader &operator=(const LineReader &) = delete;
+    // next line without its trailing run of \r / \n (python's rstrip(b"\r\n")); false at end of input.
+    // The line stays valid until the next call.
     bool next(const char *&line, size_t &len)
     {
+        if (carry_served_) {
+            carry_.clear();
+            carry_served_ = false;
+        }
         for (;;) {
-            const char *nl = (const char *)memchr(buf_.data() + pos_, '\n', end_ - pos_);
-            if (nl) {
-                line = buf_.data() + pos_;
-                len = (size_t)(nl - line);
-                pos_ = (size_t)(nl - buf_.data()) + 1;
-                while (len && (line[len - 1] == '\r' || line[len - 1] == '\n'))
-                    len--;
-                return true;
-            }
-            if (eof_) {
-                if (pos_ == end_)
-                    return false;
-                line = buf_.data() + pos_;
-                len = end_ - pos_;
-                pos_ = end_;
-                while (len && (line[len - 1] == '\r' || line[len - 1] == '\n'))
-                    len--;
-                return true;
-            }
-            // no complete line in the buffer: compact, grow if the line is longer than the buffer, read more
-            if (pos_) {
-                memmove(buf_.data(), buf_.data() + pos_, end_ - pos_);
-                end_ -= pos_;
+            if (!cur_) {
+                std::unique_lock<std::mutex> g(mu_);
+                cv_.wait(g, [&] { return !full_.empty() || eof_; });
+                if (full_.empty()) { // end of input: what is left in carry_ is the last, unterminated line
+                    if (carry_.empty())
+                        return false;
+                    line = carry_.data();
+                    len = carry_.size();
+                    carry_served_ = true;
+                    strip(line, len);
+                    return true;
+                }
+                cur_ = full_.front();
+                full_.pop_front();
                 pos_ = 0;
             }
-            if (buf_.size() - end_ < READ_CHUNK)
-                buf_.resize(buf_.size() * 2);
-            ssize_t r;
-            do {
-                r = ::read(fd_, buf_.data() + end_, READ_CHUNK);
-            } while (r < 0 && errno == EINTR);
-            if (r < 0) {
-                err_ = errno;
-                eof_ = true;
-            } else if (r == 0) {
-                eof_ = true;
-            } else {
-                end_ += (size_t)r;
+            const char *base = cur_->data.data();
+            const char *nl = (const char *)memchr(base + pos_, '\n', cur_->len - pos_);
+            if (nl) {
+                if (carry_.empty()) {
+                    line = base + pos_;
+                    len = (size_t)(nl - line);
+                } else {
+                    carry_.append(base + pos_, (size_t)(nl - (base + pos_)));
+                    line = carry_.data();
+                    len = carry_.size();
+                    carry_served_ = true;
+                }
+                pos_ = (size_t)(nl - base) + 1;
+                strip(line, len);
+                return true;
             }
+            carry_.append(base + pos_, cur_->len - pos_); // no line end in the rest of this block
+            {
+                std::lock_guard<std::mutex> g(mu_);
+                free_.push_back(cur_);
+            }
+            cv_.notify_all();
+            cur_ = nullptr;
         }
     }
     int error() const { return err_; }
 
   private:
+    struct Block {
+        std::vector<char> data;
+        size_t len = 0;
+    };
+    static void strip(const char *line, size_t &len)
+    {
+        while (len && (line[len - 1] == '\r' || line[len - 1] == '\n'))
+            len--;
+    }
+    void pump()
+    {
+        for (;;) {
+            Block *b = nullptr;
+            {
+                std::unique_lock<std::mutex> g(mu_);
+                cv_.wait(g, [&] { return !free_.empty() || stop_; });
+                if (stop_)
+                    break;
+                b = free_.front();
+                free_.pop_front();
+            }
+            if (b->data.size() < READ_CHUNK)
+                b->data.resize(READ_CHUNK);
+            // wait for data in slices, so that a reader that gave up on the stream (parse error) is not held by a
+            // pipe whose writer is still alive
+            struct pollfd pf = {fd_, POLLIN, 0};
+            int pr = 0;
+            while ((pr = ::poll(&pf, 1, 50)) == 0 || (pr < 0 && errno == EINTR)) {
+                std::lock_guard<std::mutex> g(mu_);
+                if (stop_)
+                    break;
+            }
+            ssize_t r = 0;
+            {
+                std::lock_guard<std::mutex> g(mu_);
+                if (stop_)
+                    break;
+            }
+            do {
+                r = ::read(fd_, b->data.data(), READ_CHUNK);
+            } while (r < 0 && errno == EINTR);
+            std::lock_guard<std::mutex> g(mu_);
+            if (r <= 0) {
+                if (r < 0)
+                    err_ = errno;
+                eof_ = true;
+                cv_.notify_all();
+                break;
+            }
+            b->len = (size_t)r;
+            full_.push_back(b);
+            cv_.notify_all();
+        }
+        std::lock_guard<std::mutex> g(mu_);
+        eof_ = true;
+        cv_.notify_all();
+    }
+
     int fd_;
-    std::vector<char> buf_;
-    size_t pos_ = 0, end_ = 0;
-    bool eof_ = false;
+    Block pool_[3];
+    std::deque<Block *> free_, full_;
+    std::mutex mu_;
+    std::condition_variable cv_;
+    std::thread io_;
+    bool stop_ = false, eof_ = false;
+    Block *cur_ = nullptr;
+    size_t pos_ = 0;
+    std::string carry_;
+    bool carry_served_ = false;
     int err_ = 0;
 };
 
