@@ -1362,8 +1362,12 @@ static int part_finish_impl(brx_counter *c, uint32_t abundance, hipStream_t s, b
             const int grid = (int)(nb_hf < 256ull * 4ull ? nb_hf : 256ull * 4ull);
             hash_final_kernel<1024, 1024><<<grid, 1024, lds, s>>>(kin, poff, nb_hf, R_hf, abundance, log_t, dst->d_keylist, dst->keylist_cap,
                                                           dst->d_keylist_n);
-        } else { // one wave per bucket, 2048-entry table
-            const uint32_t log_t = 11;
+        } else { // one wave per bucket; table of 256..2048 entries, about 4x the average bucket (the clear and the
+                 // scan of the table cost every bucket T / 64 LDS accesses per lane each, its keys only n / 64)
+            // (k = 21 at 1 Gbp, 119 keys per bucket: 512 entries, 6.1 ms; with 2048 it was 17.1 ms; 2x or 3x room measure the same)
+            uint32_t log_t = 8;
+            while (log_t < 11 && (1ull << log_t) < 4 * avg)
+                log_t++;
             const size_t lds = 4 * (((size_t)4 << log_t) + hf_ebuf(64) * 8 + 16);
             const uint64_t want = (nb_hf + 3) / 4;
             const int grid = (int)(want < 256ull * 16ull ? want : 256ull * 16ull);
