@@ -137,3 +137,23 @@ def test_abundance_threshold_methods():
     import pytest
     with pytest.raises(ValueError):
         sp.get_threshold(S, "median")
+
+
+def test_fastq_and_csv_readers():
+    """host-side readers behind `solid|large-kmer -f fastq|csv` (the reference's optional features, src/set/pcon.rs:27-45,
+    114-181): four-line FASTQ records, the stream ends silently at the first malformed one; CSV: header row skipped,
+    first column, empty lines skipped, a field that is not a k-mer is an error here"""
+    import io
+    import pytest
+    from br_amd import fasta
+    fq = b"@r1 d\nACGTA\n+\nIIIII\n@r2\r\nGG\r\n+r2\r\nII\r\n@bad\nAC\n+\nI\n@r3\nAAAA\n+\nIIII\n"
+    assert list(fasta.read_fastq_sequences(io.BytesIO(fq))) == [b"ACGTA", b"GG"]
+    assert list(fasta.read_fastq_sequences(io.BytesIO(b""))) == []
+    assert list(fasta.read_fastq_sequences(io.BytesIO(b">r1\nACGT\n"))) == []          # not FASTQ: nothing
+    assert list(fasta.read_fastq_sequences(io.BytesIO(b"@r1\nACGT\n+\nIIII"))) == [b"ACGT"]   # no final newline
+    assert list(fasta.read_fastq_sequences(io.BytesIO(b"@ r1\nACGT\n+\nIIII\n"))) == []    # empty name
+    assert list(fasta.read_csv_kmers(io.BytesIO(b"kmer,count\nACG,3\n\nTTT,1\n"), 3)) == [b"ACG", b"TTT"]
+    assert list(fasta.read_csv_kmers(io.BytesIO(b"kmer\n"), 3)) == []
+    assert list(fasta.read_csv_kmers(io.BytesIO(b""), 3)) == []
+    with pytest.raises(ValueError):
+        list(fasta.read_csv_kmers(io.BytesIO(b"kmer\nACGT\n"), 3))
