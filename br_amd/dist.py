@@ -23,6 +23,41 @@ import torch.distributed as dist
 CHUNK_BYTES = 1 << 30
 
 
+# The collectives below are torch.distributed's, on device tensors over RCCL.  With the "gloo" backend (two ranks
+# rehearsing the exchange on ONE GPU, where RCCL cannot run; tests/test_gpu_parity.py) device tensors are staged
+# through host memory, since gloo's all_to_all takes CPU tensors only.
+def _staged(t: torch.Tensor) -> bool:
+    return t.is_cuda and dist.get_backend() == "gloo"
+
+
+def _all_reduce(t: torch.Tensor, op) -> None:
+    if _staged(t):
+        h = t.cpu()
+        dist.all_reduce(h, op=op)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=op)
+
+
+def _all_gather(outs, t: torch.Tensor) -> None:
+    if _staged(t):
+        hs = [torch.empty(o.shape, dtype=o.dtype) for o in outs]
+        dist.all_gather(hs, t.cpu())
+        for o, h in zip(outs, hs):
+            o.copy_(h)
+    else:
+        dist.all_gather(outs, t)
+
+
+def _all_to_all_single(out: torch.Tensor, inp: torch.Tensor, output_split_sizes, input_split_sizes) -> None:
+    if _staged(inp):
+        h = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_to_all_single(h, inp.cpu(), output_split_sizes=output_split_sizes, input_split_sizes=input_split_sizes)
+        out.copy_(h)
+    else:
+        dist.all_to_all_single(out, inp, output_split_sizes=output_split_sizes, input_split_sizes=input_split_sizes)
+
+
 class _DevBuf:
     """zero-copy torch view over a raw device pointer owned by libbrx"""
 
@@ -66,10 +101,10 @@ def allreduce_counts(counter_like, abundance: int, world: int, stream: Optional[
     for lo in range(0, n, chunk_bytes):
         part = t[lo:lo + chunk_bytes]
         if cap is not None:
-            dist.all_reduce(part, op=dist.ReduceOp.SUM)
+            _all_reduce(part, dist.ReduceOp.SUM)
         else:
             wide = part.to(torch.int32)
-            dist.all_reduce(wide, op=dist.ReduceOp.SUM)
+            _all_reduce(wide, dist.ReduceOp.SUM)
             part.copy_(wide.clamp_(max=255).to(torch.uint8))
 
 
@@ -133,7 +168,7 @@ def all_to_all_chunked(recv: torch.Tensor, send: torch.Tensor, recv_counts, send
     rounds = max([(c + chunk - 1) // chunk for c in list(send_counts) + list(recv_counts)] + [0])
     # every rank must run the same number of rounds
     t = torch.tensor([rounds], dtype=torch.int64, device=send.device)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    _all_reduce(t, dist.ReduceOp.MAX)
     rounds = int(t.item())
     for c in range(rounds):
         s_parts, r_sizes, s_sizes = [], [], []
@@ -147,7 +182,7 @@ def all_to_all_chunked(recv: torch.Tensor, send: torch.Tensor, recv_counts, send
             r_sizes.append(hi - lo)
         sbuf = torch.cat(s_parts) if world > 1 else s_parts[0].contiguous()
         rbuf = torch.empty(sum(r_sizes), dtype=recv.dtype, device=recv.device)
-        dist.all_to_all_single(rbuf, sbuf, output_split_sizes=r_sizes, input_split_sizes=s_sizes)
+        _all_to_all_single(rbuf, sbuf, r_sizes, s_sizes)
         pos = 0
         for r in range(world):
             lo = min(c * chunk, recv_counts[r])
@@ -163,7 +198,7 @@ def exchange_partitioned(engine, abundance: int, world: int, rank: int) -> None:
     B1 = l1off.numel() - 1
     bounds = owner_bounds(B1, world)
     tables = [torch.empty_like(l1off) for _ in range(world)]
-    dist.all_gather(tables, l1off)
+    _all_gather(tables, l1off)
     tab_h = [t.cpu() for t in tables]
     mine_h = tab_h[rank]
     send_counts = [int(mine_h[bounds[r + 1]] - mine_h[bounds[r]]) for r in range(world)]
@@ -183,13 +218,13 @@ def exchange_partitioned(engine, abundance: int, world: int, rank: int) -> None:
     solid = engine.extract(lo * per_bucket, (hi - lo) * per_bucket)
     n_mine = torch.tensor([solid.numel()], dtype=torch.int64, device=keys.device)
     counts = [torch.empty_like(n_mine) for _ in range(world)]
-    dist.all_gather(counts, n_mine)
+    _all_gather(counts, n_mine)
     counts_h = [int(c.item()) for c in counts]
     maxn = max(max(counts_h), 1)
     padded = torch.zeros(maxn, dtype=torch.int64, device=keys.device)
     padded[:solid.numel()] = solid
     gathered = [torch.empty_like(padded) for _ in range(world)]
-    dist.all_gather(gathered, padded)
+    _all_gather(gathered, padded)
     for s in range(world):
         if s != rank and counts_h[s]:
             engine.or_keys(gathered[s][:counts_h[s]])

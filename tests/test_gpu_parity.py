@@ -632,3 +632,45 @@ def test_cli_solid_fastq_and_csv(tmp_path, golden_dir, raw_reads):
     om = O.Solid.sparse_from_count(21, reads, 0)
     probe = [O.seq2bit(reads[3][j:j + 21]) for j in range(0, 400, 7)] + [O.seq2bit(b"ACGTTGCAACGTTGCAACGTA")]
     assert [s21.get(x) for x in probe] == [om.get(x) for x in probe]
+
+
+@pytest.mark.parametrize("k", [13, 15, 19])
+def test_two_rank_exchange_on_one_gpu(tmp_path, raw_reads, k):
+    """SetExchange.build_partitioned with world_size 2 for real: two processes share the card and talk over gloo
+    (tests/dist_gpu_worker.py); each counts its half of the reads, the keys go to their owners, the solid lists come
+    back, and each rank corrects its own shard against the set of ALL reads.  k = 13: bit vector + OR of the other
+    rank's list; k = 15: no bit vector at finish time, the probe index is built from both ranks' lists; k = 19: the
+    owner's finish is the LDS hash-count over its half of the digit range."""
+    import pickle
+    import subprocess
+    import sys
+    a, n_reads, world = 2, 60, 2
+    port = 29600 + (os.getpid() + k) % 300
+    prefix = str(tmp_path / "x")
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "dist_gpu_worker.py")
+    procs = [subprocess.Popen([sys.executable, worker, str(r), str(world), str(port), str(k), str(a), str(n_reads), prefix])
+             for r in range(world)]
+    try:
+        codes = [p.wait(timeout=240) for p in procs]
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    assert codes == [0, 0]
+    reads = raw_reads[:n_reads]
+    ref = O.Solid.from_count(k, O.count_reads(k, reads), a) if k <= 15 else O.Solid.sparse_from_count(k, reads, a)
+    om = O.build_methods(ref, ["one", "graph"], 5, 7)
+    expect = [O.correct_record(om, r, False) for r in reads]
+    got = []
+    for r in range(world):
+        with open("%s.rank%d.pkl" % (prefix, r), "rb") as f:
+            res = pickle.load(f)
+        if k <= 15:
+            assert res["solid_bytes"] == ref.to_bytes()          # every rank holds the set of all reads
+        else:
+            assert res["members"] == [ref.get(x) for x in res["sample"]]
+        assert res["corrected_0"] == res["corrected_1"]
+        if k >= 15:
+            assert res["index"]["valid"]
+        got += res["corrected_0"]
+    assert got == expect                                       # shards concatenate to the input order
