@@ -43,6 +43,9 @@ def parse():
     ap.add_argument("--strategy", default="auto", choices=["auto", "dense", "sorted"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--progress", action="store_true", help="timestamps of the stages on stderr (big configurations)")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="N > 1 ranks all on cuda:0 with the gloo backend: checks the multi-rank code path where only one "
+                         "card is available (RCCL cannot put two ranks on one GPU); the rate it prints means nothing")
     ap.add_argument("--force-exchange", action="store_true",
                     help="debug: run the multi-GPU exchange step even with one rank (RCCL, world_size 1)")
     ap.add_argument("--cpu-reads", type=int, default=0, help="reads in the CPU-baseline sample (0 = auto)")
@@ -67,8 +70,8 @@ def main():
     from br_amd import _lib, synth
 
     t_prog = time.perf_counter()
-    torch.cuda.set_device(local_rank)
-    dev = local_rank
+    dev = 0 if args.rehearse_on_one_gpu else local_rank
+    torch.cuda.set_device(dev)
     stream = torch.cuda.current_stream().cuda_stream
 
     k, a = args.k, args.abundance
@@ -97,7 +100,10 @@ def main():
     if world > 1 or args.force_exchange:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.rehearse_on_one_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     from br_amd import dist as brx_dist
     multi = world > 1 or args.force_exchange
     exchanger = brx_dist.SetExchange(world, rank) if multi else None
@@ -226,7 +232,9 @@ def main():
             "config": {"workload": "synthetic %.2f Gbp/GPU ONT-error %d bp reads, k=%d, set build (-a %d) + "
                                    "correct::%s (-C %d) fwd+rev" % (total / 1e9, read_len, k, a, args.method, args.confirm),
                        "reads_per_gpu": n_reads, "bases_per_gpu": total, "genome_len": genome_len,
-                       "strategy": args.strategy, "parallelism": "reads sharded x%d" % world},
+                       "strategy": args.strategy, "parallelism": "reads sharded x%d" % world,
+                       **({"rehearsal": "all ranks on cuda:0 over gloo: code-path check, not a measurement"}
+                          if args.rehearse_on_one_gpu else {})},
             "phases": {"build_ms_per_step": round(phase_ms["build"] / args.steps, 3),
                        "correct_ms_per_step": round(phase_ms["correct"] / args.steps, 3),
                        "correct_only_gbases_per_s": round(total * args.steps / (phase_ms["correct"] * 1e-3) / 1e9, 3)
