@@ -245,6 +245,7 @@ def main():
                         for n, v in prof.items() if v["launches"]},
             "correct_stats": {**{k_: int(v) for k_, v in stats.items()}, "out_bases": int(out_total),
                               "solid_kmers": int(solid_bits)},
+            "probe_index": gs.index_info(),
             "checks": checks,
             "roofline": roofline,
             "cpu_baseline": cpu,

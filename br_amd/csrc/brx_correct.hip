@@ -1484,9 +1484,9 @@ int brx_chain_correct_batch_device(brx_chain_t *ch, const uint8_t *d_bases, cons
     for (int m = 0; m < n_methods; m++)
         needs_path |= (ch->methods[m].method == BRX_GRAPH || ch->methods[m].method == BRX_GAP_SIZE ||
                        ch->methods[m].method == BRX_GREEDY);
-    uint32_t maxpath = 4096; // visited-list capacity per group (1 GiB of scratch at 32768 groups); grows x8 on overflow
+    uint32_t maxpath = ch->maxpath_seen; // visited-list capacity per group (4096: 1 GiB of scratch at 32768 groups); grows x8 on overflow
 
-    for (uint32_t slack = 1, attempt = 0;; attempt++) {
+    for (uint32_t slack = ch->slack_seen, attempt = 0;; attempt++) {
         if (attempt > 12) {
             set_error("correction output / graph walks do not fit the workspace after 12 enlargements; giving up");
             return BRX_ERR_OVERFLOW;
@@ -1574,6 +1574,8 @@ int brx_chain_correct_batch_device(brx_chain_t *ch, const uint8_t *d_bases, cons
                 slack *= 4;
             if (ch->h_ctrl[CTL_PATHOVF] != 0)
                 maxpath *= 8;
+            ch->slack_seen = slack;
+            ch->maxpath_seen = maxpath;
             continue;
         }
         stats[0] = ch->h_ctrl[CTL_ROUNDS];

@@ -154,5 +154,8 @@ struct brx_chain {
     uint64_t *d_out_off;
     uint64_t d_out_off_cap;
     uint64_t last_stats[8];
+    // workspace sizes that a batch of this chain has needed so far: the next batch starts from them, so that one
+    // long walk or one read that grows a lot costs its own batch a second run, not every batch after it
+    uint32_t slack_seen = 1, maxpath_seen = 4096;
     std::mutex mu;
 };

@@ -406,6 +406,9 @@ def test_output_slot_overflow_retry():
         if method == "graph":
             assert got[0] == genome[100:370] and got[1] == genome[500:960]
             assert chain.last_stats()["overflow_retries"] >= 1
+            # the chain remembers the workspace it needed: the same batch again runs once
+            assert chain.correct_reads(reads) == exp
+            assert chain.last_stats()["overflow_retries"] == 0
 
 
 def test_partitioned_exchange_primitives_two_shards(raw_reads):
