@@ -34,6 +34,16 @@ try:
             f.write(hb[int(ho[r]):int(ho[r + 1])].tobytes())
             f.write(b"\n")
     res = {"reads": n_reads, "bases": int(total), "file_bytes": os.path.getsize(src)}
+
+    def throttled():  # CFS bandwidth throttling of this container (cgroup v2), in thread-seconds
+        try:
+            with open("/sys/fs/cgroup/cpu.stat") as f:
+                d = dict(line.split() for line in f)
+            return int(d.get("nr_throttled", 0)), int(d.get("throttled_usec", 0)) / 1e6
+        except OSError:
+            return 0, 0.0
+
+    th0 = throttled()
     t0 = time.perf_counter()
     cnt = br_amd.Counter(k, 0)
     with open(src, "rb") as f:
@@ -45,6 +55,8 @@ try:
     with open(src, "rb") as fi, open(dst, "wb") as fo:
         st = run_correction([fi], [fo], methods, False, native=True)
     t2 = time.perf_counter()
+    th1 = throttled()
+    res.update({"cpu_throttle_events": th1[0] - th0[0], "cpu_throttled_thread_s": round(th1[1] - th0[1], 3)})
     res.update({"build_s": round(t1 - t0, 3), "build_gbases_per_s": round(total / (t1 - t0) / 1e9, 3),
                 "build_parse_s": round(st_c["ns_parse"] / 1e9, 3), "build_gpu_s": round(st_c["ns_gpu"] / 1e9, 3),
                 "correct_s": round(t2 - t1, 3), "correct_gbases_per_s": round(total / (t2 - t1) / 1e9, 3),
