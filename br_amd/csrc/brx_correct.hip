@@ -1406,6 +1406,11 @@ int brx_chain_new(const brx_set_t *set, const brx_method_t *methods, uint32_t n_
     ch->d_out_off = nullptr;
     ch->d_out_off_cap = 0;
     memset(ch->last_stats, 0, sizeof(ch->last_stats));
+    if (const char *e = getenv("BRX_MAXPATH")) { // tests: a short visited list, so that walks outgrow it
+        const int v = atoi(e);
+        if (v >= 1 && v <= (1 << 20))
+            ch->maxpath_seen = (uint32_t)v;
+    }
     hipError_t e = hipStreamCreateWithFlags(&ch->stream, hipStreamNonBlocking);
     if (e == hipSuccess)
         e = hipMalloc((void **)&ch->d_ctrl, CTL_N * 8);
@@ -1559,8 +1564,15 @@ int brx_chain_correct_batch_device(brx_chain_t *ch, const uint8_t *d_bases, cons
             set_error("empty method list");
             return BRX_ERR_ARG;
         }
+        static const bool tr_attempts = [] { const char *e = getenv("BRX_TRACE"); return e && *e == '1'; }();
+        if (tr_attempts)
+            fprintf(stderr, "[brx correct] attempt %u launched: slack %u maxpath %u n_reads %u\n", attempt, slack, maxpath, n_reads);
         BRX_HIP(hipMemcpyAsync(ch->h_ctrl, ch->d_ctrl, CTL_N * 8, hipMemcpyDeviceToHost, s));
         BRX_HIP(hipStreamSynchronize(s));
+        if (tr_attempts)
+            fprintf(stderr, "[brx correct] attempt %u done: slot overflows %llu, walk list overflows %llu, nonterminating %llu\n", attempt,
+                    (unsigned long long)ch->h_ctrl[CTL_OVERFLOW], (unsigned long long)ch->h_ctrl[CTL_PATHOVF],
+                    (unsigned long long)ch->h_ctrl[CTL_NONTERM]);
         stats[4] = attempt;
         if (ch->h_ctrl[CTL_NONTERM] != 0) {
             set_error("%llu read(s): the scan does not terminate (e.g. greedy moving the read cursor backwards for ever; "
@@ -1570,6 +1582,8 @@ int brx_chain_correct_batch_device(brx_chain_t *ch, const uint8_t *d_bases, cons
         if (ch->h_ctrl[CTL_OVERFLOW] != 0 || ch->h_ctrl[CTL_PATHOVF] != 0) {
             // some read outgrew its output slot / a graph walk outgrew its visited list: redo the
             // batch on the GPU with a larger workspace (never on the CPU)
+            stats[5] += ch->h_ctrl[CTL_OVERFLOW]; // reads that outgrew their slot / walks that outgrew the list,
+            stats[6] += ch->h_ctrl[CTL_PATHOVF];  // summed over the attempts that were thrown away
             if (ch->h_ctrl[CTL_OVERFLOW] != 0)
                 slack *= 4;
             if (ch->h_ctrl[CTL_PATHOVF] != 0)

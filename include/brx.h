@@ -205,7 +205,8 @@ int brx_chain_correct_batch_device(brx_chain_t *chain, const uint8_t *d_bases, c
                                    uint32_t n_reads, uint64_t total_bases, uint8_t *d_out, uint64_t out_cap,
                                    uint64_t *d_out_offsets, uint64_t *out_total, void *stream);
 /* counters of the last batch: [0] scan rounds, [1] probes issued, [2] triggers, [3] fixes,
- * [4] overflow retries (u64[8], rest reserved)                                             */
+ * [4] overflow retries, [5] reads that outgrew their output slot and [6] graph walks that outgrew the
+ * visited list in the attempts that were redone (u64[8], [7] reserved)                              */
 int brx_chain_last_stats(const brx_chain_t *chain, uint64_t *stats8);
 void brx_chain_free(brx_chain_t *chain);
 void brx_buf_free(void *p);

@@ -411,6 +411,24 @@ def test_output_slot_overflow_retry():
             assert chain.last_stats()["overflow_retries"] == 0
 
 
+def test_walk_list_overflow_retry(raw_reads, solid_fixture_bytes, monkeypatch):
+    """a walk that outgrows its visited list poisons its read; the batch is then run again with a list 8x as long
+    (BRX_MAXPATH=2: nearly every successful walk needs it, twice over) -- same bytes as the oracle, for every
+    walking method, chained and with the reverse pass; the chain keeps the longer list for the next batch"""
+    monkeypatch.setenv("BRX_MAXPATH", "2")
+    ref = O.Solid.from_bytes(solid_fixture_bytes)
+    gs = br_amd.Pcon.from_pcon_solid(solid_fixture_bytes)
+    reads = raw_reads[:24] + [b"", b"ACGT"]
+    for methods in (["graph"], ["gap_size"], ["one", "gap_size", "graph"]):
+        om = O.build_methods(ref, methods, 5, 7)
+        chain = br_amd.Chain(gs, [(m, 5, 7) for m in methods], two_side=False)
+        got = chain.correct_reads(reads)
+        assert got == [O.correct_record(om, r, False) for r in reads]
+        st = chain.last_stats()
+        assert st["overflow_retries"] >= 2 and st["walk_list_overflows"] > 0 and st["slot_overflow_reads"] == 0
+        assert chain.correct_reads(reads) == got and chain.last_stats()["overflow_retries"] == 0
+
+
 def test_partitioned_exchange_primitives_two_shards(raw_reads):
     """the data path of the multi-GPU key exchange, emulated on one GPU: two shards counted separately,
     every 'owner' receives both shards' segments of its digit range (l1_view / add_partitioned), finishes
