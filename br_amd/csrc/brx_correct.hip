@@ -27,6 +27,8 @@
 
 #include <stdlib.h>
 #include <string.h>
+#include <algorithm>
+#include <vector>
 
 using namespace brx;
 
@@ -70,7 +72,7 @@ struct PassParams {
     uint32_t g_lds_bytes; // bytes of dynamic LDS per group
 };
 
-__device__ __forceinline__ uint64_t slot_of(uint64_t o, uint64_t r, uint32_t slack)
+__host__ __device__ __forceinline__ uint64_t slot_of(uint64_t o, uint64_t r, uint32_t slack)
 {
     return o + (o >> 2) * (uint64_t)slack + 64ull * r;
 }
@@ -1425,6 +1427,86 @@ int brx_chain_new(const brx_set_t *set, const brx_method_t *methods, uint32_t n_
     return BRX_OK;
 }
 
+// A handful of reads whose graph walk outgrew the visited list (GapSize at BASELINE configs[4]'s per-GPU share: 18
+// of 625 000) should not cost the whole batch a second run.  Everything else of the batch is final and sits in its
+// own slot of the last staging buffer, so the poisoned reads are taken out as a small batch of their own, corrected
+// by a second chain with a longer list (same set, methods and direction rule; all on the GPU), and written back into
+// their slots.  BRX_OK: lens / slots patched, the batch is complete.  BRX_ERR_UNSUPPORTED: not applicable (too many
+// reads, or a corrected read does not fit its slot) -- the caller redoes the whole batch as before.
+static uint32_t redo_max_reads()
+{
+    const char *e = getenv("BRX_REDO_MAX"); // tests: 0 = never (read on every use: only overflowing batches get here)
+    return e ? (uint32_t)atoi(e) : 4096u;
+}
+static int redo_walk_overflows(brx_chain *ch, const uint8_t *d_bases, const uint64_t *d_offsets, uint32_t n_reads,
+                               uint8_t *d_stage, uint32_t *d_lens, int stage_reversed, uint32_t slack, uint32_t maxpath,
+                               hipStream_t s)
+{
+    if (ch->is_sub)
+        return BRX_ERR_UNSUPPORTED;
+    std::vector<uint32_t> lens(n_reads);
+    std::vector<uint64_t> offs((size_t)n_reads + 1);
+    BRX_HIP(hipMemcpyAsync(lens.data(), d_lens, (size_t)n_reads * 4, hipMemcpyDeviceToHost, s));
+    BRX_HIP(hipMemcpyAsync(offs.data(), d_offsets, ((size_t)n_reads + 1) * 8, hipMemcpyDeviceToHost, s));
+    BRX_HIP(hipStreamSynchronize(s));
+    std::vector<uint32_t> ids;
+    for (uint32_t r = 0; r < n_reads; r++)
+        if (lens[r] == 0xffffffffu) {
+            if (ids.size() >= redo_max_reads())
+                return BRX_ERR_UNSUPPORTED;
+            ids.push_back(r);
+        }
+    if (ids.empty())
+        return BRX_ERR_UNSUPPORTED;
+    std::vector<uint64_t> moff(ids.size() + 1, 0);
+    for (size_t j = 0; j < ids.size(); j++)
+        moff[j + 1] = moff[j] + (offs[ids[j] + 1] - offs[ids[j]]);
+    std::vector<uint8_t> mb(moff.back() ? moff.back() : 1);
+    for (size_t j = 0; j < ids.size(); j++)
+        if (moff[j + 1] > moff[j])
+            BRX_HIP(hipMemcpyAsync(mb.data() + moff[j], d_bases + offs[ids[j]], moff[j + 1] - moff[j], hipMemcpyDeviceToHost, s));
+    BRX_HIP(hipStreamSynchronize(s));
+    if (!ch->sub) {
+        brx_chain *sub = nullptr;
+        BRX_TRY(brx_chain_new(ch->set, ch->methods.data(), (uint32_t)ch->methods.size(), ch->two_side, &sub));
+        sub->is_sub = true;
+        ch->sub = sub;
+    }
+    if (ch->sub->maxpath_seen < maxpath)
+        ch->sub->maxpath_seen = maxpath;
+    uint8_t *ob = nullptr;
+    uint64_t *oo = nullptr;
+    BRX_TRY(brx_chain_correct_batch(ch->sub, mb.data(), moff.data(), (uint32_t)ids.size(), &ob, &oo));
+    int st = BRX_OK;
+    std::vector<uint8_t> rev;
+    for (size_t j = 0; j < ids.size() && st == BRX_OK; j++) {
+        const uint32_t r = ids[j];
+        const uint64_t s0 = slot_of(offs[r], r, slack), s1 = slot_of(offs[r + 1], (uint64_t)r + 1, slack);
+        const uint64_t len = oo[j + 1] - oo[j];
+        if (len + 1 > s1 - s0 || len >= 0xffffffffull) {
+            st = BRX_ERR_UNSUPPORTED; // the corrected read does not fit its slot: the whole batch, with more slack
+            break;
+        }
+        const uint8_t *src = ob + oo[j];
+        if (stage_reversed) { // the last pass stored its reads back to front
+            rev.assign(src, src + len);
+            std::reverse(rev.begin(), rev.end());
+            src = rev.data();
+        }
+        const uint32_t l32 = (uint32_t)len;
+        hipError_t e = len ? hipMemcpy(d_stage + s0, src, len, hipMemcpyHostToDevice) : hipSuccess;
+        if (e == hipSuccess)
+            e = hipMemcpy(d_lens + r, &l32, 4, hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            set_error("redo of walk-list overflows: %s", hipGetErrorString(e));
+            st = BRX_ERR_HIP;
+        }
+    }
+    brx_buf_free(ob);
+    brx_buf_free(oo);
+    return st;
+}
+
 int brx_chain_correct_batch_device(brx_chain_t *ch, const uint8_t *d_bases, const uint64_t *d_offsets,
                                    uint32_t n_reads, uint64_t total_bases, uint8_t *d_out, uint64_t out_cap,
                                    uint64_t *d_out_offsets, uint64_t *out_total, void *stream)
@@ -1583,14 +1665,27 @@ int brx_chain_correct_batch_device(brx_chain_t *ch, const uint8_t *d_bases, cons
             // some read outgrew its output slot / a graph walk outgrew its visited list: redo the
             // batch on the GPU with a larger workspace (never on the CPU)
             stats[5] += ch->h_ctrl[CTL_OVERFLOW]; // reads that outgrew their slot / walks that outgrew the list,
-            stats[6] += ch->h_ctrl[CTL_PATHOVF];  // summed over the attempts that were thrown away
-            if (ch->h_ctrl[CTL_OVERFLOW] != 0)
-                slack *= 4;
-            if (ch->h_ctrl[CTL_PATHOVF] != 0)
-                maxpath *= 8;
-            ch->slack_seen = slack;
-            ch->maxpath_seen = maxpath;
-            continue;
+            stats[6] += ch->h_ctrl[CTL_PATHOVF];  // summed over the attempts that were thrown away or patched
+            bool patched = false;
+            if (ch->h_ctrl[CTL_OVERFLOW] == 0 && ch->h_ctrl[CTL_PATHOVF] <= redo_max_reads()) {
+                const int rst = redo_walk_overflows(ch, d_bases, d_offsets, n_reads, const_cast<uint8_t *>(cur),
+                                                    const_cast<uint32_t *>(cur_lens), cur_rev, slack, maxpath * 8u, s);
+                if (rst == BRX_OK) {
+                    patched = true;
+                    ch->maxpath_seen = maxpath * 8u; // the next batch of this chain starts with the longer list
+                }
+                else if (rst != BRX_ERR_UNSUPPORTED)
+                    return rst;
+            }
+            if (!patched) {
+                if (ch->h_ctrl[CTL_OVERFLOW] != 0)
+                    slack *= 4;
+                if (ch->h_ctrl[CTL_PATHOVF] != 0)
+                    maxpath *= 8;
+                ch->slack_seen = slack;
+                ch->maxpath_seen = maxpath;
+                continue;
+            }
         }
         stats[0] = ch->h_ctrl[CTL_ROUNDS];
         stats[1] = ch->h_ctrl[CTL_PROBES];
@@ -1692,6 +1787,9 @@ void brx_chain_free(brx_chain_t *ch)
 {
     if (!ch)
         return;
+    if (ch->sub)
+        brx_chain_free(ch->sub);
+    ch->sub = nullptr;
     if (use_device(ch->device) == BRX_OK) {
         for (int q = 0; q < 2; q++) {
             if (ch->d_stage[q])

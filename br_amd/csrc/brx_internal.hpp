@@ -157,5 +157,9 @@ struct brx_chain {
     // workspace sizes that a batch of this chain has needed so far: the next batch starts from them, so that one
     // long walk or one read that grows a lot costs its own batch a second run, not every batch after it
     uint32_t slack_seen = 1, maxpath_seen = 4096;
+    // second chain (same set, methods and direction rule, its own workspace) that redoes the few reads of a batch
+    // whose graph walks outgrew the visited list; created on first need
+    brx_chain *sub = nullptr;
+    bool is_sub = false;
     std::mutex mu;
 };

@@ -411,11 +411,15 @@ def test_output_slot_overflow_retry():
             assert chain.last_stats()["overflow_retries"] == 0
 
 
-def test_walk_list_overflow_retry(raw_reads, solid_fixture_bytes, monkeypatch):
-    """a walk that outgrows its visited list poisons its read; the batch is then run again with a list 8x as long
-    (BRX_MAXPATH=2: nearly every successful walk needs it, twice over) -- same bytes as the oracle, for every
-    walking method, chained and with the reverse pass; the chain keeps the longer list for the next batch"""
+@pytest.mark.parametrize("redo_max", ["4096", "0"])
+def test_walk_list_overflow_retry(raw_reads, solid_fixture_bytes, monkeypatch, redo_max):
+    """a walk that outgrows its visited list poisons its read (BRX_MAXPATH=2: nearly every successful walk does).  Up
+    to 4096 such reads are taken out, corrected by a second chain with a longer list and written back into their slots
+    (the rest of the batch is final); more than that (BRX_REDO_MAX=0 forces it) and the whole batch runs again with a
+    list 8x as long, which the chain then keeps.  Either way: the oracle's bytes, for every walking method, chained,
+    with the reverse pass."""
     monkeypatch.setenv("BRX_MAXPATH", "2")
+    monkeypatch.setenv("BRX_REDO_MAX", redo_max)
     ref = O.Solid.from_bytes(solid_fixture_bytes)
     gs = br_amd.Pcon.from_pcon_solid(solid_fixture_bytes)
     reads = raw_reads[:24] + [b"", b"ACGT"]
@@ -425,8 +429,13 @@ def test_walk_list_overflow_retry(raw_reads, solid_fixture_bytes, monkeypatch):
         got = chain.correct_reads(reads)
         assert got == [O.correct_record(om, r, False) for r in reads]
         st = chain.last_stats()
-        assert st["overflow_retries"] >= 2 and st["walk_list_overflows"] > 0 and st["slot_overflow_reads"] == 0
-        assert chain.correct_reads(reads) == got and chain.last_stats()["overflow_retries"] == 0
+        assert st["walk_list_overflows"] > 0 and st["slot_overflow_reads"] == 0
+        if redo_max == "0":
+            assert st["overflow_retries"] >= 2
+            assert chain.correct_reads(reads) == got and chain.last_stats()["overflow_retries"] == 0
+        else:
+            assert st["overflow_retries"] == 0
+            assert chain.correct_reads(reads) == got          # (the chain starts its next batch with a longer list)
 
 
 def test_partitioned_exchange_primitives_two_shards(raw_reads):
