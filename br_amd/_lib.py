@@ -83,6 +83,14 @@ SIGNATURES = {
     "brx_counter_l1_view": (C.c_int, [_vp, _pp, _pp, C.POINTER(C.c_uint32), _u64p]),
     "brx_counter_add_partitioned_device": (C.c_int, [_vp, _vp, _vp, C.c_uint64]),
     "brx_counter_free": (None, [_vp]),
+    "brx_comm_unique_id": (C.c_int, [_vp]),
+    "brx_comm_init": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _pp]),
+    "brx_comm_init_all": (C.c_int, [C.c_int, C.POINTER(C.c_int), _pp]),
+    "brx_comm_info": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "brx_exchange_build_partitioned": (C.c_int, [_vp, _vp, C.c_uint8, _vp, _vp]),
+    "brx_exchange_reduce_counts": (C.c_int, [_vp, _vp, C.c_uint8, _vp]),
+    "brx_comm_last_stats": (C.c_int, [_vp, _u64p]),
+    "brx_comm_free": (None, [_vp]),
     "brx_chain_new": (C.c_int, [_vp, C.POINTER(Method), C.c_uint32, C.c_bool, _pp]),
     "brx_chain_correct_batch": (C.c_int, [_vp, _vp, _vp, C.c_uint32, C.POINTER(_u8p), C.POINTER(_u64p)]),
     "brx_chain_correct_batch_device": (C.c_int, [_vp, _vp, _vp, C.c_uint32, C.c_uint64, _vp, C.c_uint64, _vp,

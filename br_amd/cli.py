@@ -33,6 +33,18 @@ from .set import Counter, Pcon
 METHOD_NAMES = ["one", "two", "graph", "greedy", "gap-size"]  # clap ValueEnum kebab-case of CorrectionMethod
 
 
+
+def u8(text: str) -> int:
+    """clap parses -a / -C / -M into u8 fields (src/cli.rs:46,50,196): out-of-range values are rejected, not wrapped"""
+    try:
+        v = int(text)
+    except ValueError:
+        raise argparse.ArgumentTypeError("invalid digit found in string: %r" % text)
+    if not 0 <= v <= 255:
+        raise argparse.ArgumentTypeError("%r is not in 0..=255" % text)
+    return v
+
+
 def open_input(path: str) -> BinaryIO:
     """niffler::get_reader: sniff gz / bz2 / xz by magic bytes (src/cli.rs:209,269,404,415)."""
     raw = open(path, "rb")
@@ -56,8 +68,8 @@ def parser() -> argparse.ArgumentParser:
     p.add_argument("-s", "--two-side", action="store_true", help="Correct in two side (sic: disables the reverse pass)")
     p.add_argument("-c", "--corrections", action="append", choices=METHOD_NAMES, default=None,
                    help="Correction method")
-    p.add_argument("-C", "--confirm", type=int, default=None, help="Number of kmer required to validate correction")
-    p.add_argument("-M", "--max-search", type=int, default=None, help="Number of base we use to try correct error")
+    p.add_argument("-C", "--confirm", type=u8, default=None, help="Number of kmer required to validate correction")
+    p.add_argument("-M", "--max-search", type=u8, default=None, help="Number of base we use to try correct error")
     p.add_argument("-b", "--record_buffer", type=int, default=None, help="Number of sequence record load in buffer")
     p.add_argument("-t", "--threads", type=int, default=None, help="accepted for compatibility, ignored")
     p.add_argument("-q", "--quiet", action="store_true")
@@ -74,12 +86,12 @@ def parser() -> argparse.ArgumentParser:
 
     c = sub.add_parser("count", help="With Count")
     c.add_argument("-i", "--inputs", dest="sub_inputs", required=True)
-    c.add_argument("-a", "--abundance", type=int, default=None)
+    c.add_argument("-a", "--abundance", type=u8, default=None)
     abundance_methods(c)
     f = sub.add_parser("fasta", help="With Fasta")
     f.add_argument("-i", "--inputs", dest="sub_inputs", action="append", required=True)
     f.add_argument("-k", "--kmer-size", type=int, required=True)
-    f.add_argument("-a", "--abundance", type=int, default=None)
+    f.add_argument("-a", "--abundance", type=u8, default=None)
     abundance_methods(f)
     s = sub.add_parser("solid", help="With Solid")
     s.add_argument("-i", "--input", dest="sub_input", required=True)

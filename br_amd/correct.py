@@ -23,6 +23,8 @@ class Chain:
         self.solid = solid  # keep the set alive (the reference borrows it: src/lib.rs:143)
         arr = (_lib.Method * max(len(methods), 1))()
         for i, (name, confirm, max_search) in enumerate(methods):
+            if not (0 <= int(confirm) <= 255 and 0 <= int(max_search) <= 255):
+                raise ValueError(f"confirm={confirm} / max_search={max_search}: u8 in the reference (src/cli.rs:46,50)")
             arr[i].method = _lib.METHOD_IDS[name]
             arr[i].confirm = confirm
             arr[i].max_search = max_search

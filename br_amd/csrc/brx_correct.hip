@@ -1507,16 +1507,12 @@ static int redo_walk_overflows(brx_chain *ch, const uint8_t *d_bases, const uint
     return st;
 }
 
-int brx_chain_correct_batch_device(brx_chain_t *ch, const uint8_t *d_bases, const uint64_t *d_offsets,
-                                   uint32_t n_reads, uint64_t total_bases, uint8_t *d_out, uint64_t out_cap,
-                                   uint64_t *d_out_offsets, uint64_t *out_total, void *stream)
+// the batch entry proper; the caller holds ch->mu (a chain owns ONE workspace: staging buffers, control block, visited
+// lists -- two batches at once on one chain would share them)
+static int correct_batch_device_locked(brx_chain_t *ch, const uint8_t *d_bases, const uint64_t *d_offsets,
+                                       uint32_t n_reads, uint64_t total_bases, uint8_t *d_out, uint64_t out_cap,
+                                       uint64_t *d_out_offsets, uint64_t *out_total, void *stream)
 {
-    if (!ch || !d_offsets || !d_out_offsets || !out_total || (!d_bases && total_bases) || (!d_out && out_cap)) {
-        set_error("null argument");
-        return BRX_ERR_ARG;
-    }
-    BRX_TRY(use_device(ch->device));
-    std::lock_guard<std::mutex> g(ch->mu);
     hipStream_t s = (hipStream_t)stream; // nullptr = the legacy default stream
     *out_total = 0;
     if (n_reads == 0) {
@@ -1579,7 +1575,10 @@ int brx_chain_correct_batch_device(brx_chain_t *ch, const uint8_t *d_bases, cons
             return BRX_ERR_OVERFLOW;
         }
         if (needs_path) {
-            const uint64_t n_groups = (uint64_t)MAX_BLOCKS * 16u; // upper bound over every group width used by walking methods
+            // one visited list per group that can be resident: walking methods run 16-lane groups or wider, so a grid of
+            // pass_blocks(n_reads, 16) blocks of 16 groups bounds every width (a handful of redone reads needs a
+            // handful of lists, not 32768 of them)
+            const uint64_t n_groups = (uint64_t)pass_blocks(n_reads, 16) * 16u;
             BRX_TRY(ensure((void **)&ch->d_path, &ch->path_bytes, n_groups * maxpath * 8ull));
         }
         const uint64_t stage_need = total_bases + (total_bases >> 2) * slack + 64ull * ((uint64_t)n_reads + 1) + 64;
@@ -1671,8 +1670,12 @@ int brx_chain_correct_batch_device(brx_chain_t *ch, const uint8_t *d_bases, cons
                 const int rst = redo_walk_overflows(ch, d_bases, d_offsets, n_reads, const_cast<uint8_t *>(cur),
                                                     const_cast<uint32_t *>(cur_lens), cur_rev, slack, maxpath * 8u, s);
                 if (rst == BRX_OK) {
+                    // the few long walks were redone by the sub chain with its own longer list; this chain keeps its
+                    // list size (growing it x8 for every group of the grid is 8 GiB per chain after one event)
                     patched = true;
-                    ch->maxpath_seen = maxpath * 8u; // the next batch of this chain starts with the longer list
+                    if (ch->sub) // events of the redone reads, which the first attempt gave up on
+                        for (int q = 0; q < 4; q++)
+                            stats[q] += ch->sub->last_stats[q];
                 }
                 else if (rst != BRX_ERR_UNSUPPORTED)
                     return rst;
@@ -1687,10 +1690,10 @@ int brx_chain_correct_batch_device(brx_chain_t *ch, const uint8_t *d_bases, cons
                 continue;
             }
         }
-        stats[0] = ch->h_ctrl[CTL_ROUNDS];
-        stats[1] = ch->h_ctrl[CTL_PROBES];
-        stats[2] = ch->h_ctrl[CTL_TRIGGERS];
-        stats[3] = ch->h_ctrl[CTL_FIXES];
+        stats[0] += ch->h_ctrl[CTL_ROUNDS];
+        stats[1] += ch->h_ctrl[CTL_PROBES];
+        stats[2] += ch->h_ctrl[CTL_TRIGGERS];
+        stats[3] += ch->h_ctrl[CTL_FIXES];
 
         // out_offsets = exclusive scan of final lengths
         BRX_TRY(exclusive_scan_lens(cur_lens, n_reads, ch->d_scan_tmp, d_out_offsets,
@@ -1715,6 +1718,20 @@ int brx_chain_correct_batch_device(brx_chain_t *ch, const uint8_t *d_bases, cons
     }
 }
 
+int brx_chain_correct_batch_device(brx_chain_t *ch, const uint8_t *d_bases, const uint64_t *d_offsets,
+                                   uint32_t n_reads, uint64_t total_bases, uint8_t *d_out, uint64_t out_cap,
+                                   uint64_t *d_out_offsets, uint64_t *out_total, void *stream)
+{
+    if (!ch || !d_offsets || !d_out_offsets || !out_total || (!d_bases && total_bases) || (!d_out && out_cap)) {
+        set_error("null argument");
+        return BRX_ERR_ARG;
+    }
+    BRX_TRY(use_device(ch->device));
+    std::lock_guard<std::mutex> g(ch->mu);
+    return correct_batch_device_locked(ch, d_bases, d_offsets, n_reads, total_bases, d_out, out_cap, d_out_offsets, out_total,
+                                       stream);
+}
+
 int brx_chain_correct_batch(brx_chain_t *ch, const uint8_t *bases, const uint64_t *offsets, uint32_t n_reads,
                             uint8_t **out_bases, uint64_t **out_offsets)
 {
@@ -1725,11 +1742,12 @@ int brx_chain_correct_batch(brx_chain_t *ch, const uint8_t *bases, const uint64_
     *out_bases = nullptr;
     *out_offsets = nullptr;
     BRX_TRY(use_device(ch->device));
+    // ONE lock from the upload to the download: the chain's own d_in / d_off / d_out staging is part of the workspace
+    // a concurrent call on the same chain would overwrite (include/brx.h: "a chain serialises concurrent calls")
+    std::lock_guard<std::mutex> g(ch->mu);
     uint64_t total = 0;
+    BRX_TRY(upload_batch(bases, offsets, n_reads, &ch->d_in, &ch->d_in_cap, &ch->d_off, &ch->d_off_cap, &total, ch->stream));
     {
-        std::lock_guard<std::mutex> g(ch->mu);
-        BRX_TRY(upload_batch(bases, offsets, n_reads, &ch->d_in, &ch->d_in_cap, &ch->d_off, &ch->d_off_cap, &total,
-                             ch->stream));
         uint64_t cap_b = ch->d_out_off_cap * 8;
         BRX_TRY(ensure((void **)&ch->d_out_off, &cap_b, ((uint64_t)n_reads + 1) * 8));
         ch->d_out_off_cap = cap_b / 8;
@@ -1737,12 +1755,9 @@ int brx_chain_correct_batch(brx_chain_t *ch, const uint8_t *bases, const uint64_
     uint64_t out_total = 0;
     uint64_t want = total + total / 16 + 4096;
     for (int attempt = 0; attempt < 3; attempt++) {
-        {
-            std::lock_guard<std::mutex> g(ch->mu);
-            BRX_TRY(ensure((void **)&ch->d_out, &ch->d_out_cap, want));
-        }
-        int st = brx_chain_correct_batch_device(ch, ch->d_in, ch->d_off, n_reads, total, ch->d_out, ch->d_out_cap,
-                                                ch->d_out_off, &out_total, ch->stream);
+        BRX_TRY(ensure((void **)&ch->d_out, &ch->d_out_cap, want));
+        int st = correct_batch_device_locked(ch, ch->d_in, ch->d_off, n_reads, total, ch->d_out, ch->d_out_cap, ch->d_out_off,
+                                             &out_total, ch->stream);
         if (st == BRX_ERR_OVERFLOW && out_total > ch->d_out_cap) {
             want = out_total + 64;
             continue;

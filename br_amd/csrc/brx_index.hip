@@ -24,7 +24,9 @@ __global__ __launch_bounds__(256) void index_insert_kernel(const uint64_t *__res
         const uint64_t rc = revcomp(canon, k);
         uint32_t line = index_line_of(minimizer_of(canon, rc, m, w), line_shift);
         bool counted = false;
-        for (;;) {
+        // a chained walk visits at most every line once (the host checks that the table has room for its keys;
+        // this bound keeps a mis-sized table from spinning the GPU for ever: the key is then simply lost and counted)
+        for (uint32_t walked = 0; walked <= line_mask; walked++) {
             unsigned long long *L = reinterpret_cast<unsigned long long *>(lines) + (uint64_t)line * 8ull;
             const unsigned long long seen = __hip_atomic_load(L + 7, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             uint32_t slot = IDX_SLOTS;
@@ -176,6 +178,12 @@ static int index_build_locked(brx_set *set, const uint64_t *d_keys, uint64_t n, 
     if (log_lines < 4 || log_lines > 30) {
         set_error("probe index: log2(lines)=%d out of range 4..30", log_lines);
         return BRX_ERR_ARG;
+    }
+    if (no_bits(set) && (7ull << log_lines) < n + n / 4) {
+        // a chained table that cannot hold its keys would send index_insert_kernel<true> round the table for ever
+        set_error("set without bit vector: %llu solid k-mers do not fit a chained table of 2^%d lines (7 slots each)",
+                  (unsigned long long)n, log_lines);
+        return BRX_ERR_NOMEM;
     }
     set->idx_valid = false;
     const uint64_t n_lines = 1ull << log_lines;

@@ -128,6 +128,57 @@ class SetExchange:
         eng.release()
 
 
+class AbiExchange:
+    """The exchange step behind the C ABI (include/brx.h brx_comm_* / brx_exchange_*): libbrx calls librccl itself
+    (ncclSend/ncclRecv groups for the key all-to-all, all-gather of the solid-hash lists).  All this class adds is
+    the hand-over of the 128-byte communicator id from rank 0 to the other ranks, through the process group the
+    host already has (any out-of-band channel would do)."""
+
+    def __init__(self, world: int, rank: int, device: int):
+        import ctypes as C
+        from . import _lib
+        self.world, self.rank, self.device = world, rank, device
+        L = _lib.lib()
+        ident = (C.c_uint8 * 128)()
+        if rank == 0:
+            _lib.check(L.brx_comm_unique_id(ident))
+        if world > 1:
+            box = [bytes(ident)]
+            dist.broadcast_object_list(box, src=0)
+            ident = (C.c_uint8 * 128).from_buffer_copy(box[0])
+        self._h = C.c_void_p()
+        _lib.check(L.brx_comm_init(ident, world, rank, device, C.byref(self._h)))
+
+    def build_partitioned(self, counter, solid, abundance: int, stream: Optional[int] = None) -> None:
+        from . import _lib
+        _lib.check(_lib.lib().brx_exchange_build_partitioned(self._h, counter._h, abundance, solid._h, stream))
+
+    def reduce_counts(self, counter, abundance: int, stream: Optional[int] = None) -> None:
+        from . import _lib
+        _lib.check(_lib.lib().brx_exchange_reduce_counts(self._h, counter._h, abundance, stream))
+
+    def last_stats(self) -> dict:
+        import ctypes as C
+        from . import _lib
+        v = (C.c_uint64 * 8)()
+        _lib.check(_lib.lib().brx_comm_last_stats(self._h, v))
+        names = ["key_bytes_sent", "key_bytes_received", "keys_counted_here", "solid_here", "solid_job", "all_to_all_us",
+                 "exchange_us", "largest_message_keys"]
+        return dict(zip(names, [int(x) for x in v]))
+
+    def close(self) -> None:
+        from . import _lib
+        if getattr(self, "_h", None) and self._h.value:
+            _lib.lib().brx_comm_free(self._h)
+            self._h.value = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def shard_range(n_items: int, world: int, rank: int):
     """contiguous block of records for a rank: concatenating the ranks restores input order"""
     lo = n_items * rank // world

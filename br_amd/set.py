@@ -14,6 +14,11 @@ import numpy as np
 from . import _lib
 
 
+def _check_u8(v: int, what: str) -> None:
+    if not 0 <= int(v) <= 255:  # u8 in the reference (src/cli.rs:196); ctypes would wrap it silently
+        raise ValueError(f"{what}={v} does not fit the reference's u8")
+
+
 def pack_reads(reads: Sequence[bytes]) -> Tuple[np.ndarray, np.ndarray]:
     """records -> (bases uint8[total], offsets uint64[n+1]): the batch layout of include/brx.h."""
     offs = np.zeros(len(reads) + 1, dtype=np.uint64)
@@ -310,10 +315,12 @@ class Counter:
         _lib.check(_lib.lib().brx_counter_reset(self._h, stream))
 
     def finish_into(self, abundance: int, dst: "Pcon", stream: Optional[int] = None) -> None:
+        _check_u8(abundance, "abundance")
         _lib.check(_lib.lib().brx_set_count_finish_into(self._h, abundance, stream, dst._h))
 
     def finish(self, abundance: int, stream: Optional[int] = None) -> Pcon:
         """Solid::from_count(k, counts, abundance): solid iff count > abundance."""
+        _check_u8(abundance, "abundance")
         h = C.c_void_p()
         _lib.check(_lib.lib().brx_set_count_finish(self._h, abundance, stream, C.byref(h)))
         return Pcon(h.value, self.device)

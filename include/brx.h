@@ -186,6 +186,37 @@ int brx_counter_l1_view(brx_counter_t *c, void **d_keys, void **d_l1off, uint32_
 int brx_counter_add_partitioned_device(brx_counter_t *c, const uint32_t *d_keys, const uint64_t *d_l1off, uint64_t n_keys);
 void brx_counter_free(brx_counter_t *c);
 
+/* ---- multi-GPU: reads shard over the GPUs, the set is exchanged ONCE -----------------------------
+ * The reference is one process with rayon threads over shared memory (src/main.rs:30-33, src/lib.rs:72-139); on N
+ * GPUs every rank counts and later corrects its own block of the reads, and the single exchange step is the k-mer
+ * counts.  It runs inside this library over RCCL (xGMI), so a host needs no collective library of its own:
+ *   - one process per GPU: rank 0 calls brx_comm_unique_id and hands the 128 bytes to the other ranks by any means
+ *     it has (file, socket, MPI, torch.distributed); every rank then calls brx_comm_init(id, world, rank, device);
+ *   - one process driving several GPUs (the reference's shape): brx_comm_init_all(n, devices, comms[n]), then one
+ *     host thread per GPU.
+ * librccl is dlopen'ed by soname on first use (BRX_RCCL_PATH overrides); BRX_ERR_UNSUPPORTED if it cannot be found. */
+typedef struct brx_comm brx_comm_t;
+#define BRX_COMM_ID_BYTES 128
+int brx_comm_unique_id(uint8_t *id128);
+int brx_comm_init(const uint8_t *id128, int world, int rank, int device, brx_comm_t **out);
+int brx_comm_init_all(int n_devices, const int *devices, brx_comm_t **out /* n_devices handles */);
+int brx_comm_info(const brx_comm_t *comm, int *world, int *rank, int *device);
+/* `c` (partitioned strategy) has counted this rank's reads in ONE add_batch.  Every rank calls this once, together:
+ * the canonical hashes go to the rank owning their first radix digit (all-to-all of u32 keys), the owner finishes its
+ * digit range with `count > abundance`, and every owner's solid hashes go to everybody (all-gather of u64 lists).  On
+ * return `dst` holds the solid set of ALL ranks' reads -- what the reference's all-reduce of the count vector followed
+ * by Solid::from_count gives (src/main.rs:112-114) -- its probe index is built, and `c` is empty again.  k=19, 1 Gbp
+ * per GPU: ~3.5 GB of keys + 0.15 GB of lists per rank over xGMI instead of 120 GB + 15 GB for the u8 vector.   */
+int brx_exchange_build_partitioned(brx_comm_t *comm, brx_counter_t *c, uint8_t abundance, brx_set_t *dst, void *stream);
+/* dense strategy, north_star's form: in-place all-reduce of the 2^(2k-1)-byte u8 table, exact for `count >
+ * abundance` (counts are clamped to abundance+1 first; int32 slices once world*(abundance+1) > 255); the caller
+ * then runs brx_set_count_finish[_into] on every rank.                                                          */
+int brx_exchange_reduce_counts(brx_comm_t *comm, brx_counter_t *c, uint8_t abundance, void *stream);
+/* last build_partitioned: [0] key bytes sent, [1] received, [2] keys counted by this owner, [3] its solid k-mers,
+ * [4] solid k-mers of the job, [5] all-to-all us, [6] whole call us, [7] largest single message (keys)          */
+int brx_comm_last_stats(const brx_comm_t *comm, uint64_t *stats8);
+void brx_comm_free(brx_comm_t *comm);
+
 /* ---- correction: src/lib.rs:22-139 (run_correction) + src/correct/mod.rs:44-108 ----------
  * brx_chain_new = build_methods (order kept, duplicates allowed).  two_side=true means the
  * -s flag was given, i.e. the reverse pass is SKIPPED (src/lib.rs:48,110).                  */

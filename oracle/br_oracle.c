@@ -1342,3 +1342,151 @@ void bro_solid_mask(const bro_solid *s, const uint8_t *seq, size_t n, uint8_t *m
             mask_bytes[j >> 3] |= (uint8_t)(1u << (j & 7));
     }
 }
+
+/* ------------------------------------------------------------------------- */
+/* multi-threaded drivers: the CPU baseline of bench.py (never the product).  */
+/* The reference's `parallel` feature runs one rayon task per record of an    */
+/* 8192-record batch (lib.rs:90-96) and pcon counts into AtomicU8 cells       */
+/* (main.rs:73-78); here pthread workers pull blocks of records from an       */
+/* atomic cursor.  Results are those of the serial functions above.           */
+/* ------------------------------------------------------------------------- */
+#include <pthread.h>
+
+typedef struct {
+    const bro_solid *set;
+    const int *methods;
+    int n_methods, c, max_search, two_side;
+    const uint8_t *bases;
+    const uint64_t *offsets;
+    uint32_t n_reads, block;
+    uint32_t *cursor;      /* shared */
+    uint64_t *out_lens;    /* per read, may be NULL */
+    uint64_t out_bases;    /* per thread */
+    uint64_t fixes;        /* per thread */
+    uint8_t *counts;       /* counting job */
+    int k;
+} mt_job;
+
+static void *mt_correct_worker(void *arg)
+{
+    mt_job *j = (mt_job *)arg;
+    bro_corrector *ms[16];
+    for (int m = 0; m < j->n_methods; m++)
+        ms[m] = bro_corrector_new(j->set, j->methods[m], j->c, j->max_search);
+    for (;;) {
+        uint32_t lo = __atomic_fetch_add(j->cursor, j->block, __ATOMIC_RELAXED);
+        if (lo >= j->n_reads)
+            break;
+        uint32_t hi = lo + j->block < j->n_reads ? lo + j->block : j->n_reads;
+        for (uint32_t r = lo; r < hi; r++) {
+            size_t n;
+            uint8_t *cbuf = bro_correct_record(ms, j->n_methods, j->two_side, j->bases + j->offsets[r],
+                                               (size_t)(j->offsets[r + 1] - j->offsets[r]), &n);
+            free(cbuf);
+            if (j->out_lens)
+                j->out_lens[r] = n;
+            j->out_bases += n;
+        }
+    }
+    for (int m = 0; m < j->n_methods; m++) {
+        j->fixes += ms[m]->st.fixes;
+        bro_corrector_free(ms[m]);
+    }
+    return NULL;
+}
+
+/* corrects every read with the method chain on n_threads threads; returns total corrected bytes,
+ * out_lens[r] (optional) = corrected length of read r, *fixes (optional) = Some(..) returns      */
+uint64_t bro_correct_batch_mt(const bro_solid *set, const int *methods, int n_methods, int c, int max_search,
+                              int two_side, const uint8_t *bases, const uint64_t *offsets, uint32_t n_reads,
+                              int n_threads, uint64_t *out_lens, uint64_t *fixes)
+{
+    if (n_threads < 1)
+        n_threads = 1;
+    if (n_methods > 16)
+        n_methods = 16;
+    uint32_t cursor = 0;
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)n_threads);
+    mt_job *jobs = (mt_job *)calloc((size_t)n_threads, sizeof(mt_job));
+    for (int t = 0; t < n_threads; t++) {
+        jobs[t].set = set;
+        jobs[t].methods = methods;
+        jobs[t].n_methods = n_methods;
+        jobs[t].c = c;
+        jobs[t].max_search = max_search;
+        jobs[t].two_side = two_side;
+        jobs[t].bases = bases;
+        jobs[t].offsets = offsets;
+        jobs[t].n_reads = n_reads;
+        jobs[t].block = 16;
+        jobs[t].cursor = &cursor;
+        jobs[t].out_lens = out_lens;
+        pthread_create(&th[t], NULL, mt_correct_worker, &jobs[t]);
+    }
+    uint64_t total = 0, fx = 0;
+    for (int t = 0; t < n_threads; t++) {
+        pthread_join(th[t], NULL);
+        total += jobs[t].out_bases;
+        fx += jobs[t].fixes;
+    }
+    if (fixes)
+        *fixes = fx;
+    free(jobs);
+    free(th);
+    return total;
+}
+
+static void *mt_count_worker(void *arg)
+{
+    mt_job *j = (mt_job *)arg;
+    const int k = j->k;
+    for (;;) {
+        uint32_t lo = __atomic_fetch_add(j->cursor, j->block, __ATOMIC_RELAXED);
+        if (lo >= j->n_reads)
+            break;
+        uint32_t hi = lo + j->block < j->n_reads ? lo + j->block : j->n_reads;
+        for (uint32_t r = lo; r < hi; r++) {
+            const uint8_t *seq = j->bases + j->offsets[r];
+            size_t n = (size_t)(j->offsets[r + 1] - j->offsets[r]);
+            if (n < (size_t)k)
+                continue;
+            uint64_t kmer = bro_seq2bit(seq, (size_t)k);
+            for (size_t i = (size_t)k;; i++) {
+                uint8_t *cell = j->counts + bro_hash(kmer, k);
+                uint8_t v = __atomic_load_n(cell, __ATOMIC_RELAXED); /* saturating AtomicU8 increment */
+                while (v != 255 && !__atomic_compare_exchange_n(cell, &v, (uint8_t)(v + 1), 1, __ATOMIC_RELAXED,
+                                                                __ATOMIC_RELAXED))
+                    ;
+                if (i >= n)
+                    break;
+                kmer = add_nuc_to_end(kmer, bro_nuc2bit(seq[i]), k);
+            }
+        }
+    }
+    return NULL;
+}
+
+/* Counter::count_fasta on n_threads threads into a caller-zeroed 2^(2k-1)-byte table (same table as bro_count_seq) */
+void bro_count_batch_mt(uint8_t *counts, int k, const uint8_t *bases, const uint64_t *offsets, uint32_t n_reads,
+                        int n_threads)
+{
+    if (n_threads < 1)
+        n_threads = 1;
+    uint32_t cursor = 0;
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)n_threads);
+    mt_job *jobs = (mt_job *)calloc((size_t)n_threads, sizeof(mt_job));
+    for (int t = 0; t < n_threads; t++) {
+        jobs[t].counts = counts;
+        jobs[t].k = k;
+        jobs[t].bases = bases;
+        jobs[t].offsets = offsets;
+        jobs[t].n_reads = n_reads;
+        jobs[t].block = 16;
+        jobs[t].cursor = &cursor;
+        pthread_create(&th[t], NULL, mt_count_worker, &jobs[t]);
+    }
+    for (int t = 0; t < n_threads; t++)
+        pthread_join(th[t], NULL);
+    free(jobs);
+    free(th);
+}

@@ -77,6 +77,9 @@ def lib():
         "bro_free": (None, [vp]),
         "bro_solid_mask": (None, [vp, vp, C.c_size_t, vp]),
         "bro_bio_global": (C.c_size_t, [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, vp]),
+        "bro_correct_batch_mt": (C.c_uint64, [vp, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.c_int, vp, vp,
+                                              C.c_uint32, C.c_int, vp, u64p]),
+        "bro_count_batch_mt": (None, [vp, C.c_int, vp, vp, C.c_uint32, C.c_int]),
     }
     for name, (res, args) in sig.items():
         f = getattr(L, name)
@@ -278,6 +281,32 @@ def correct_batch(methods: Sequence[Corrector], bases: np.ndarray, offsets: np.n
     out = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(max(total, 1),))[:total].copy()
     L.bro_free(p)
     return out, out_off
+
+
+def correct_batch_mt(solid: Solid, methods: Sequence[str], bases: np.ndarray, offsets: np.ndarray, confirm: int = 5,
+                     max_search: int = 7, two_side: bool = False, threads: int = 1):
+    """the chain over every read on `threads` pthreads (bench.py's CPU baseline): returns (corrected lengths per
+    read, total corrected bytes, fixes); the corrected bytes themselves are dropped."""
+    bases = np.ascontiguousarray(bases, dtype=np.uint8)
+    offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+    n = offsets.size - 1
+    ids = (C.c_int * len(methods))(*[METHODS[m] for m in methods])
+    lens = np.zeros(max(n, 1), dtype=np.uint64)
+    fixes = C.c_uint64(0)
+    total = lib().bro_correct_batch_mt(solid._h, ids, len(methods), confirm, max_search, 1 if two_side else 0,
+                                       bases.ctypes.data, offsets.ctypes.data, n, threads, lens.ctypes.data,
+                                       C.byref(fixes))
+    return lens[:n], int(total), int(fixes.value)
+
+
+def count_reads_mt(k: int, bases: np.ndarray, offsets: np.ndarray, threads: int = 1) -> np.ndarray:
+    """count_reads on `threads` pthreads (saturating atomic u8 cells): same table"""
+    L = lib()
+    bases = np.ascontiguousarray(bases, dtype=np.uint8)
+    offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+    counts = np.zeros(L.bro_count_nbytes(k), dtype=np.uint8)
+    L.bro_count_batch_mt(counts.ctypes.data, k, bases.ctypes.data, offsets.ctypes.data, offsets.size - 1, threads)
+    return counts
 
 
 def alt_nucs(solid: Solid, kmer: int) -> List[int]:

@@ -157,3 +157,28 @@ def test_fastq_and_csv_readers():
     assert list(fasta.read_csv_kmers(io.BytesIO(b""), 3)) == []
     with pytest.raises(ValueError):
         list(fasta.read_csv_kmers(io.BytesIO(b"kmer\nACGT\n"), 3))
+
+
+def test_c_host_links_without_python_or_torch():
+    """tests/abi_smoke (plain C, gcc) links libbrx.so and gets libamdhip64 through libbrx's own RUNPATH; with no
+    GPU it must say so and exit 4 (no CPU fallback), not crash on a missing library"""
+    import subprocess
+    exe = os.path.join(ROOT, "tests", "abi_smoke")
+    if not os.path.exists(exe):
+        pytest.skip("tests/abi_smoke not built (__graft_entry__.build())")
+    if _lib.device_count() > 0:
+        pytest.skip("GPU present: covered by test_gpu_parity.py::test_abi_smoke_c_host")
+    env = {k: v for k, v in os.environ.items() if k not in ("LD_LIBRARY_PATH", "PYTHONPATH")}
+    r = subprocess.run([exe, "a", "b", "c", "0"], capture_output=True, text=True, env=env, timeout=60)
+    assert r.returncode == 4 and "no GPU visible" in r.stderr, (r.returncode, r.stderr)
+
+
+def test_cli_rejects_values_outside_u8():
+    """-a / -C / -M are u8 in the reference (src/cli.rs:46,50,196): clap rejects 256, it does not wrap to 0"""
+    from br_amd import cli
+    for argv in (["-C", "256", "solid", "-i", "x", "-f", "solid"], ["-M", "-1", "solid", "-i", "x", "-f", "solid"],
+                 ["fasta", "-i", "x", "-k", "11", "-a", "300"]):
+        with pytest.raises(SystemExit):
+            cli.parser().parse_args(argv)
+    with pytest.raises(ValueError):
+        br_amd.set._check_u8(300, "abundance")

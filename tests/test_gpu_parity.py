@@ -704,3 +704,90 @@ def test_two_rank_exchange_on_one_gpu(tmp_path, raw_reads, k):
             assert res["index"]["valid"]
         got += res["corrected_0"]
     assert got == expect                                       # shards concatenate to the input order
+
+
+# ---------------------------------------------------------------- boundary ----------------------
+def test_abi_smoke_c_host(tmp_path, raw_reads, solid_fixture_bytes):
+    """A host with no Python and no torch in its process (tests/abi_smoke.c, plain C built by gcc) links libbrx.so,
+    loads the reference's k=11 fixture, corrects 20 reads with the reference's default chain and compares with the
+    bytes the oracle wrote to a file -- what a Rust `br` binding does."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "tests", "abi_smoke")
+    assert os.path.exists(exe), "tests/abi_smoke not built: __graft_entry__.build()"
+    reads = raw_reads[:20]
+    bases, offs = br_amd.pack_reads(reads)
+    s = O.Solid.from_bytes(solid_fixture_bytes)
+    (tmp_path / "set.solid").write_bytes(solid_fixture_bytes)
+    (tmp_path / "reads.bin").write_bytes(np.uint32(len(reads)).tobytes() + offs.tobytes() + bases.tobytes())
+    env = {k: v for k, v in os.environ.items() if k not in ("LD_LIBRARY_PATH", "PYTHONPATH", "LD_PRELOAD")}
+    for ids, names, two_side in (("0", ["one"], 0), ("0,1,2,3,4", ["one", "two", "graph", "greedy", "gap_size"], 0),
+                                 ("2,4", ["graph", "gap_size"], 1)):
+        exp, exp_o = O.correct_batch(O.build_methods(s, names, 5, 7), bases, offs, bool(two_side))
+        (tmp_path / "expect.bin").write_bytes(exp_o.tobytes() + exp.tobytes())
+        r = subprocess.run([exe, str(tmp_path / "set.solid"), str(tmp_path / "reads.bin"), str(tmp_path / "expect.bin"), ids,
+                            str(two_side)], capture_output=True, text=True, env=env, timeout=300)
+        assert r.returncode == 0 and "identical to the oracle" in r.stdout, (ids, r.returncode, r.stdout, r.stderr)
+
+
+def test_two_host_threads_on_one_chain(raw_reads, solid_fixture_bytes):
+    """include/brx.h: "a brx_chain_t owns its workspace and serialises concurrent calls" -- two host threads pushing
+    different batches through ONE chain (host-pointer entry: upload, correct, download) each get their own result"""
+    import threading
+    gs = br_amd.Pcon.from_pcon_solid(solid_fixture_bytes)
+    s = O.Solid.from_bytes(solid_fixture_bytes)
+    chain = br_amd.Chain(gs, [("one", 5, 7), ("graph", 5, 7)], two_side=False)
+    jobs = [raw_reads[0:30], raw_reads[30:45], raw_reads[45:90], raw_reads[90:100]]
+    packed = [br_amd.pack_reads(j) for j in jobs]
+    expect = [O.correct_batch(O.build_methods(s, ["one", "graph"], 5, 7), b, o, False) for b, o in packed]
+    results = [None] * len(jobs)
+    errors = []
+
+    def work(tid):
+        try:
+            for rep in range(3):
+                for j in range(tid, len(jobs), 2):
+                    results[j] = chain.correct_batch(*packed[j])
+        except Exception as e:  # pragma: no cover
+            errors.append(e)
+
+    ts = [threading.Thread(target=work, args=(t,)) for t in range(2)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errors, errors
+    for (out, oo), (exp, exp_o) in zip(results, expect):
+        assert np.array_equal(oo, exp_o) and np.array_equal(out, exp)
+
+
+def test_exchange_behind_the_abi_single_rank():
+    """brx_comm_* / brx_exchange_build_partitioned (librccl called from libbrx.so) with a world of one: the keys go
+    through ncclSend/ncclRecv to self, the lists through the all-gather, and the set equals the plain finish"""
+    import ctypes as C
+    from br_amd import dist as D
+    k, a = 15, 2
+    cfg = synth.config(genome_len=60_000, read_len=3_000)
+    g = synth.genome_host(cfg)
+    bases, offs = synth.reads_host(cfg, g, 0, 400)
+    plain = br_amd.Counter(k, 0, _lib.COUNT_SORTED)
+    plain.add_batch(bases, offs)
+    ref = plain.finish(a)
+    os.environ["BRX_EXCHANGE_SELF_SEND"] = "1"
+    try:
+        ex = D.AbiExchange(1, 0, 0)
+        for chunk in ("0", "100000"):       # one message / many rounds of capped messages
+            os.environ["BRX_A2A_CHUNK"] = chunk
+            cnt = br_amd.Counter(k, 0, _lib.COUNT_SORTED)
+            cnt.add_batch(bases, offs)
+            gs = br_amd.Pcon.new(k, 0)
+            ex.build_partitioned(cnt, gs, a, None)
+            st = ex.last_stats()
+            assert st["solid_job"] == ref.popcount() == gs.popcount() and st["keys_counted_here"] > 0
+            assert gs.to_solid_bytes() == ref.to_solid_bytes()
+            # and the set corrects like the plain one (its probe index came from the gathered list)
+            c1 = br_amd.Chain(gs, [("one", 5, 7)], two_side=False).correct_batch(bases, offs)
+            c2 = br_amd.Chain(ref, [("one", 5, 7)], two_side=False).correct_batch(bases, offs)
+            assert np.array_equal(c1[0], c2[0]) and np.array_equal(c1[1], c2[1])
+        ex.close()
+    finally:
+        os.environ.pop("BRX_EXCHANGE_SELF_SEND", None)
+        os.environ.pop("BRX_A2A_CHUNK", None)

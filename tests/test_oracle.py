@@ -157,3 +157,19 @@ def test_sparse_solid_equals_bitset_solid(raw_reads):
         ms = O.build_methods(sparse, [method], 5, 7)
         for r in raw_reads[:12]:
             assert O.correct_record(md, r, False) == O.correct_record(ms, r, False)
+
+
+def test_threaded_drivers_equal_the_serial_ones(raw_reads, solid_fixture_bytes):
+    """bench.py's CPU baseline runs bro_correct_batch_mt / bro_count_batch_mt (pthreads): same results as the
+    serial functions every parity test uses"""
+    import br_amd
+    reads = raw_reads[:24]
+    bases, offs = br_amd.pack_reads(reads)
+    s = O.Solid.from_bytes(solid_fixture_bytes)
+    for methods in (["one"], ["graph", "gap_size"]):
+        exp, exp_o = O.correct_batch(O.build_methods(s, methods, 5, 7), bases, offs, False)
+        lens, total, fixes = O.correct_batch_mt(s, methods, bases, offs, 5, 7, False, threads=4)
+        assert total == int(exp_o[-1]) and np.array_equal(lens, np.diff(exp_o)) and fixes > 0
+    c1 = O.count_reads(11, reads)
+    c4 = O.count_reads_mt(11, bases, offs, threads=4)
+    assert np.array_equal(c1, c4)
