@@ -350,6 +350,37 @@ def main():
         dist.destroy_process_group()
 
 
+def usable_cpus():
+    """host cores this process may really use: the affinity mask, cut down to the cgroup's CPU quota when the box is
+    shared (a one-GPU lease of an 8-GPU host sees all its cores in nproc but is scheduled on its share of them)"""
+    n = os.cpu_count() or 1
+    how = "nproc"
+    try:
+        a = len(os.sched_getaffinity(0))
+        if a < n:
+            n, how = a, "sched_getaffinity"
+    except AttributeError:
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                txt = f.read().split()
+            if path.endswith("cpu.max"):
+                quota, period = txt[0], int(txt[1])
+            else:
+                quota = txt[0]
+                with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f2:
+                    period = int(f2.read())
+            if quota not in ("max", "-1"):
+                q = max(1, int(int(quota) / period + 0.5))
+                if q < n:
+                    n, how = q, "cgroup cpu quota (%s)" % path
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n, how
+
+
 def cpu_baseline(args, cfg, gs, k, n_reads):
     """Times the CPU oracle (restatement of the reference's path; the Rust reference itself cannot be built
     offline) on a bounded sample of the same workload, with pthread workers on every core of the box
@@ -362,11 +393,8 @@ def cpu_baseline(args, cfg, gs, k, n_reads):
     from br_amd import synth
     from oracle import oracle as O
 
-    cores = args.cpu_threads or (os.cpu_count() or 1)
-    try:
-        cores = min(cores, len(os.sched_getaffinity(0))) if not args.cpu_threads else cores
-    except AttributeError:
-        pass
+    usable, how = usable_cpus()
+    cores = args.cpu_threads or usable
     per_read_s = {"one": 1.6e-3, "two": 4e-3, "graph": 3e-3, "greedy": 6e-3, "gap_size": 3e-3}
     want_s = 12.0
     est = sum(per_read_s.get(m, 3e-3) for m in args.methods)
@@ -391,7 +419,7 @@ def cpu_baseline(args, cfg, gs, k, n_reads):
     dt = time.perf_counter() - t0
     nb = int(offs[S])
     res = {"value": round(nb / dt / 1e9, 5), "unit": "Gbases/s", "cores": cores, "nproc": os.cpu_count(),
-           "kind": "port",
+           "cores_how": how, "kind": "port",
            "sample": "%s fwd+rev of the first %d reads (%.1f Mbp) against %s; correction phase only, %d pthreads "
                      "pulling 16-record blocks, %.1f s, %d fixes" % (" + ".join(args.methods), S, nb / 1e6, set_desc, cores, dt, fixes)}
     # set-build leg

@@ -1074,21 +1074,9 @@ size_t bro_bio_global(const uint8_t *x, size_t m, const uint8_t *y, size_t n, ui
     return bio_global(x, m, y, n, ops);
 }
 
-/* Greedy::match_alignement: greedy.rs:56-89.  returns 1 and *off if Some */
-static int greedy_match_alignment(const uint8_t *before, size_t nb, const uint8_t *read, size_t nr,
-                                  const uint8_t *corr, size_t nc, int64_t *off)
+/* what greedy.rs:66-86 derives from alignment.operations: 1 and *off for Some(off), 0 for None */
+static int greedy_outcome(const uint8_t *ops, size_t nops, size_t nb, int64_t *off)
 {
-    size_t m = nb + nr, n = nb + nc;
-    uint8_t *r = (uint8_t *)malloc(m + 1), *c = (uint8_t *)malloc(n + 1);
-    memcpy(r, before, nb);
-    memcpy(r + nb, read, nr);
-    memcpy(c, before, nb);
-    memcpy(c + nb, corr, nc);
-    uint8_t *ops = (uint8_t *)malloc(m + n + 2);
-    size_t nops = bio_global(r, m, c, n, ops);
-    free(r);
-    free(c);
-    int found = 0;
     int64_t offset = 0;
     /* operations[before_seq.len()..].windows(2) */
     if (nops >= nb) {
@@ -1110,11 +1098,209 @@ static int greedy_match_alignment(const uint8_t *before, size_t nb, const uint8_
                         break;
                 }
                 *off = offset - offset_corr;
-                found = 1;
-                break;
+                return 1;
             }
         }
     }
+    return 0;
+}
+
+/* ---- audit of the UNPINNED part of Greedy ------------------------------------------------------------------
+ * bio_global above restates rust-bio's tie-breaks from memory of its published algorithm; no reference test pins
+ * them.  What IS certain is that Aligner::global returns AN optimal alignment under the scoring (match +1, mismatch
+ * -1, a gap of length L costs -1 - L).  So: enumerate EVERY optimal operation sequence of a call and derive
+ * greedy.rs:66-86's result from each.  If they all agree, the result of that call does not depend on any tie-break
+ * -- it is pinned by arithmetic.  The audit counts the calls (and the correct_error invocations) where they differ. */
+typedef struct {
+    uint64_t calls;          /* match_alignement calls                                          */
+    uint64_t multi;          /* ... with more than one optimal operation sequence                */
+    uint64_t ambiguous;      /* ... whose optimal sequences give different results               */
+    uint64_t capped;         /* ... with more sequences than the enumeration cap (counted ambiguous) */
+    uint64_t restated_not_optimal; /* bio_global's own sequence is not among the optimal ones (would be a bug) */
+    uint64_t triggers;       /* Greedy correct_error invocations that aligned at least once      */
+    uint64_t triggers_amb;   /* ... containing an ambiguous call                                 */
+    uint64_t fixes;          /* ... that returned Some                                           */
+    uint64_t fixes_amb;      /* ... and contained an ambiguous call                              */
+    uint64_t max_sequences;  /* largest number of optimal sequences seen in one call             */
+} greedy_audit_t;
+static greedy_audit_t g_audit;
+static int g_audit_on = 0;
+static int g_audit_trigger_amb = 0, g_audit_trigger_calls = 0;
+
+void bro_greedy_audit_enable(int on)
+{
+    g_audit_on = on;
+    if (on)
+        memset(&g_audit, 0, sizeof(g_audit));
+}
+void bro_greedy_audit_get(uint64_t *out10)
+{
+    memcpy(out10, &g_audit, sizeof(g_audit));
+}
+
+#define AUD_MAXDIM 72
+#define AUD_CAP 200000
+typedef struct {
+    const uint8_t *x, *y;
+    int m, n;
+    size_t nb;
+    int S[AUD_MAXDIM][AUD_MAXDIM], I[AUD_MAXDIM][AUD_MAXDIM], D[AUD_MAXDIM][AUD_MAXDIM];
+    uint8_t rev[2 * AUD_MAXDIM]; /* operations from the end */
+    uint8_t fwd[2 * AUD_MAXDIM];
+    uint64_t count;
+    int have, some0;   /* first outcome seen */
+    int64_t off0;
+    int differ;
+    const uint8_t *mine; /* bio_global's sequence */
+    size_t nmine;
+    int mine_found;
+} aud_t;
+#define AUD_NEG (-100000)
+
+static void aud_leaf(aud_t *a, int nrev)
+{
+    a->count++;
+    for (int q = 0; q < nrev; q++)
+        a->fwd[q] = a->rev[nrev - 1 - q];
+    int64_t off = 0;
+    int some = greedy_outcome(a->fwd, (size_t)nrev, a->nb, &off);
+    if (!a->have) {
+        a->have = 1;
+        a->some0 = some;
+        a->off0 = off;
+    } else if (some != a->some0 || (some && off != a->off0)) {
+        a->differ = 1;
+    }
+    if ((size_t)nrev == a->nmine && memcmp(a->fwd, a->mine, a->nmine) == 0)
+        a->mine_found = 1;
+}
+
+/* layer: 0 = S, 1 = I (consumes x), 2 = D (consumes y) */
+static void aud_walk(aud_t *a, int i, int j, int layer, int nrev)
+{
+    if (a->count > AUD_CAP)
+        return;
+    const int go = -1, ge = -1;
+    if (layer == 0) {
+        if (i == 0 && j == 0) {
+            aud_leaf(a, nrev);
+            return;
+        }
+        if (i > 0 && j > 0) {
+            int eq = a->x[i - 1] == a->y[j - 1];
+            if (a->S[i][j] == a->S[i - 1][j - 1] + (eq ? 1 : -1)) {
+                a->rev[nrev] = eq ? OP_MATCH : OP_SUBST;
+                aud_walk(a, i - 1, j - 1, 0, nrev + 1);
+            }
+        }
+        if (i > 0 && a->S[i][j] == a->I[i][j])
+            aud_walk(a, i, j, 1, nrev);
+        if (j > 0 && a->S[i][j] == a->D[i][j])
+            aud_walk(a, i, j, 2, nrev);
+    } else if (layer == 1) {
+        a->rev[nrev] = OP_INS;
+        if (i > 1 && a->I[i][j] == a->I[i - 1][j] + ge)
+            aud_walk(a, i - 1, j, 1, nrev + 1);
+        if (a->I[i][j] == a->S[i - 1][j] + go + ge) {
+            /* leaving the gap: the cell before it must not itself end in the same gap layer, or the same operation
+             * sequence would be produced twice with a worse score -- S[i-1][j] is the best over all layers, fine */
+            aud_walk(a, i - 1, j, 0, nrev + 1);
+        }
+    } else {
+        a->rev[nrev] = OP_DEL;
+        if (j > 1 && a->D[i][j] == a->D[i][j - 1] + ge)
+            aud_walk(a, i, j - 1, 2, nrev + 1);
+        if (a->D[i][j] == a->S[i][j - 1] + go + ge)
+            aud_walk(a, i, j - 1, 0, nrev + 1);
+    }
+}
+
+/* returns the number of optimal operation sequences (AUD_CAP+1 = more); *differ = their greedy.rs:66-86 results
+ * are not all the same; *mine_found = `mine` (an operation sequence, forward order) is one of them */
+uint64_t bro_greedy_tie_check(const uint8_t *x, size_t m, const uint8_t *y, size_t n, size_t nb, const uint8_t *mine,
+                              size_t nmine, int *differ, int *mine_found)
+{
+    if (m + 1 > AUD_MAXDIM || n + 1 > AUD_MAXDIM) {
+        *differ = 1;
+        *mine_found = 0;
+        return AUD_CAP + 1;
+    }
+    aud_t *a = (aud_t *)calloc(1, sizeof(aud_t));
+    const int go = -1, ge = -1;
+    a->x = x;
+    a->y = y;
+    a->m = (int)m;
+    a->n = (int)n;
+    a->nb = nb;
+    a->mine = mine;
+    a->nmine = nmine;
+    for (int i = 0; i <= (int)m; i++)
+        for (int j = 0; j <= (int)n; j++) {
+            int s = AUD_NEG, ii = AUD_NEG, dd = AUD_NEG;
+            if (i == 0 && j == 0)
+                s = 0;
+            if (i > 0) {
+                int e1 = a->I[i - 1][j] + ge, e2 = a->S[i - 1][j] + go + ge;
+                ii = e1 > e2 ? e1 : e2;
+            }
+            if (j > 0) {
+                int e1 = a->D[i][j - 1] + ge, e2 = a->S[i][j - 1] + go + ge;
+                dd = e1 > e2 ? e1 : e2;
+            }
+            if (i > 0 && j > 0) {
+                int d = a->S[i - 1][j - 1] + (x[i - 1] == y[j - 1] ? 1 : -1);
+                if (d > s)
+                    s = d;
+            }
+            if (ii > s)
+                s = ii;
+            if (dd > s)
+                s = dd;
+            a->S[i][j] = s;
+            a->I[i][j] = ii < AUD_NEG ? AUD_NEG : ii;
+            a->D[i][j] = dd < AUD_NEG ? AUD_NEG : dd;
+        }
+    aud_walk(a, (int)m, (int)n, 0, 0);
+    uint64_t cnt = a->count;
+    *differ = a->differ || cnt > AUD_CAP;
+    *mine_found = a->mine_found;
+    free(a);
+    return cnt;
+}
+
+/* Greedy::match_alignement: greedy.rs:56-89.  returns 1 and *off if Some */
+static int greedy_match_alignment(const uint8_t *before, size_t nb, const uint8_t *read, size_t nr,
+                                  const uint8_t *corr, size_t nc, int64_t *off)
+{
+    size_t m = nb + nr, n = nb + nc;
+    uint8_t *r = (uint8_t *)malloc(m + 1), *c = (uint8_t *)malloc(n + 1);
+    memcpy(r, before, nb);
+    memcpy(r + nb, read, nr);
+    memcpy(c, before, nb);
+    memcpy(c + nb, corr, nc);
+    uint8_t *ops = (uint8_t *)malloc(m + n + 2);
+    size_t nops = bio_global(r, m, c, n, ops);
+    int found = greedy_outcome(ops, nops, nb, off);
+    if (g_audit_on) {
+        int differ = 0, mine_found = 0;
+        uint64_t cnt = bro_greedy_tie_check(r, m, c, n, nb, ops, nops, &differ, &mine_found);
+        g_audit.calls++;
+        g_audit_trigger_calls++;
+        if (cnt > 1)
+            g_audit.multi++;
+        if (cnt > AUD_CAP)
+            g_audit.capped++;
+        if (differ) {
+            g_audit.ambiguous++;
+            g_audit_trigger_amb = 1;
+        }
+        if (!mine_found && cnt <= AUD_CAP)
+            g_audit.restated_not_optimal++;
+        if (cnt > g_audit.max_sequences)
+            g_audit.max_sequences = cnt;
+    }
+    free(r);
+    free(c);
     free(ops);
     return found;
 }
@@ -1133,6 +1319,8 @@ static void greedy_correct_error(bro_corrector *x, uint64_t kmer, const uint8_t 
     u64set viewed;
     us_init(&viewed);
     uint8_t before[40];
+    g_audit_trigger_amb = 0;
+    g_audit_trigger_calls = 0;
     bro_kmer2seq(kmer >> 2, k - 1, before);
     kmer = add_nuc_to_end(kmer >> 2, alts[0], k);
     bv_push(&r->local, bro_bit2nuc(alts[0]));
@@ -1171,12 +1359,22 @@ static void greedy_correct_error(bro_corrector *x, uint64_t kmer, const uint8_t 
                 r->some = 1;
                 r->offset = (size_t)((int64_t)r->local.n + off); /* `as usize`: wraps when negative */
                 us_free(&viewed);
+                if (g_audit_on) {
+                    g_audit.triggers++;
+                    g_audit.fixes++;
+                    g_audit.triggers_amb += (uint64_t)g_audit_trigger_amb;
+                    g_audit.fixes_amb += (uint64_t)g_audit_trigger_amb;
+                }
                 return;
             }
         }
     }
     us_free(&viewed);
     r->local.n = 0;
+    if (g_audit_on && g_audit_trigger_calls) {
+        g_audit.triggers++;
+        g_audit.triggers_amb += (uint64_t)g_audit_trigger_amb;
+    }
 }
 
 static void correct_error(bro_corrector *x, uint64_t kmer, const uint8_t *seq, size_t len, cerr_t *r)

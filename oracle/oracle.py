@@ -77,6 +77,10 @@ def lib():
         "bro_free": (None, [vp]),
         "bro_solid_mask": (None, [vp, vp, C.c_size_t, vp]),
         "bro_bio_global": (C.c_size_t, [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, vp]),
+        "bro_greedy_audit_enable": (None, [C.c_int]),
+        "bro_greedy_audit_get": (None, [u64p]),
+        "bro_greedy_tie_check": (C.c_uint64, [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_size_t, vp, C.c_size_t,
+                                              C.POINTER(C.c_int), C.POINTER(C.c_int)]),
         "bro_correct_batch_mt": (C.c_uint64, [vp, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.c_int, vp, vp,
                                               C.c_uint32, C.c_int, vp, u64p]),
         "bro_count_batch_mt": (None, [vp, C.c_int, vp, vp, C.c_uint32, C.c_int]),
@@ -307,6 +311,31 @@ def count_reads_mt(k: int, bases: np.ndarray, offsets: np.ndarray, threads: int 
     counts = np.zeros(L.bro_count_nbytes(k), dtype=np.uint8)
     L.bro_count_batch_mt(counts.ctypes.data, k, bases.ctypes.data, offsets.ctypes.data, offsets.size - 1, threads)
     return counts
+
+
+AUDIT_FIELDS = ["calls", "multi", "ambiguous", "capped", "restated_not_optimal", "triggers", "triggers_amb", "fixes",
+                "fixes_amb", "max_sequences"]
+
+
+def greedy_audit(enable: bool) -> None:
+    """switch the tie-break audit of Greedy's alignments on (counters zeroed) or off; single-threaded use only"""
+    lib().bro_greedy_audit_enable(1 if enable else 0)
+
+
+def greedy_audit_counters() -> dict:
+    a = (C.c_uint64 * 10)()
+    lib().bro_greedy_audit_get(a)
+    return dict(zip(AUDIT_FIELDS, [int(v) for v in a]))
+
+
+def greedy_tie_check(x: bytes, y: bytes, nb: int):
+    """(number of optimal operation sequences of global(x, y), their greedy.rs:66-86 results differ, the restated
+    traceback is one of them)"""
+    ops = np.zeros(len(x) + len(y) + 2, dtype=np.uint8)
+    n = lib().bro_bio_global(x, len(x), y, len(y), ops.ctypes.data)
+    d, f = C.c_int(0), C.c_int(0)
+    cnt = lib().bro_greedy_tie_check(x, len(x), y, len(y), nb, ops.ctypes.data, n, C.byref(d), C.byref(f))
+    return int(cnt), bool(d.value), bool(f.value)
 
 
 def alt_nucs(solid: Solid, kmer: int) -> List[int]:
