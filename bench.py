@@ -424,7 +424,8 @@ def cpu_baseline(args, cfg, gs, k, n_reads):
                      "pulling 16-record blocks, %.1f s, %d fixes" % (" + ".join(args.methods), S, nb / 1e6, set_desc, cores, dt, fixes)}
     # set-build leg
     kb = min(k, 17)
-    Sb = int(min(S, max(64, 6.0 * cores / 0.06)))     # ~60 ms per 10 kb read-thread at DRAM-latency-bound 6 M RMW/s
+    Sb = int(min(S, 1600 * cores))     # ~0.1 ms per 10 kb read on one thread (DRAM-latency-bound RMW): a few seconds, so that
+    #                                    the fixed 2^(2k-1)-byte zero fill + threshold pass does not swamp the counting
     try:
         t0 = time.perf_counter()
         counts = O.count_reads_mt(kb, bases[:int(offs[Sb])], offs[:Sb + 1], cores)

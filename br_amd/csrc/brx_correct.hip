@@ -28,6 +28,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
+#include <type_traits>
 #include <vector>
 
 using namespace brx;
@@ -350,7 +351,9 @@ __device__ __forceinline__ uint32_t scen_width(uint32_t sub, uint32_t c, int G, 
 {
     const uint32_t left = c - sub;
     const uint32_t alive = 3u - (uint32_t)__popc(failmask & 7u);
-    const uint32_t cap = (sub == 0u && !(flags & 4u)) ? 2u : (uint32_t)G / (alive ? alive : 1u);
+    // G / alive without a division (a variable u32 division is ~25 VALU instructions, paid by the whole wave)
+    const uint32_t share = alive <= 1u ? (uint32_t)G : (alive == 2u ? (uint32_t)G / 2u : (uint32_t)G / 3u);
+    const uint32_t cap = (sub == 0u && !(flags & 4u)) ? (share < 2u ? share : 2u) : share;
     return left < cap ? left : cap;
 }
 
@@ -573,11 +576,12 @@ __global__ __launch_bounds__(256, (M == BRX_ONE ? (G == 64 ? 7 : 6) : (M == BRX_
                 const uint32_t width = scen_width(sub, c, G, p.flags, failmask);
                 const uint32_t e = (uint32_t)gl;
                 const uint32_t alive = ~failmask & 7u; // never 0 here
-                const uint32_t ord = e / width;        // which surviving scenario this lane works for
-                sc_active = ord < (uint32_t)__popc(alive);
+                // which surviving scenario this lane works for: e / width by two compares (at most three scenarios)
+                const uint32_t ord = (e >= width ? 1u : 0u) + (e >= 2u * width ? 1u : 0u);
+                sc_active = e < 3u * width && ord < (uint32_t)__popc(alive);
                 const uint32_t a1 = alive & (alive - 1u);
                 sc_s = !sc_active ? 0u : (ord == 0u ? (uint32_t)__ffs(alive) - 1u : (ord == 1u ? (uint32_t)__ffs(a1) - 1u : 2u));
-                const uint32_t j = sub + (sc_active ? e % width : 0u);
+                const uint32_t j = sub + (sc_active ? e - ord * width : 0u);
                 const uint32_t off = 2u - sc_s; // I:2 S:1 D:0 (one.rs:57-63)
                 if (sc_active) {
                     if (c + 3u <= (uint32_t)WB && !(p.flags & 8u)) {
@@ -1211,6 +1215,532 @@ __global__ __launch_bounds__(256, (M == BRX_ONE ? (G == 64 ? 7 : 6) : (M == BRX_
     }
 }
 
+// ======================================================================================================================
+// correct::One, second form (the metric's kernel).  Same rounds, same probes, same bytes out as correct_kernel<G, BRX_ONE>;
+// what changed is how many instructions a round costs.  rocprofv3's SQ counters showed the first form issue-bound, not
+// memory-bound (VALU busy ~75 % of every SIMD's cycles, 27 of 64 lanes active: profiles/r1k_sq_summary.json), and
+// tools/valu_rate.hip showed every VALU instruction costs the same issue slot while a ds_bpermute costs six:
+//   - the lanes' k-mers come from a DPP row_shr scan of 2-bit codes in 32-bit registers (2 instructions per step, no
+//     LDS crossbar) instead of a 64-bit __shfl_up scan (8 per step);
+//   - the group's next k-mer after a SCAN round is cut from the group's code window (one 32-bit broadcast issued before
+//     the probe's memory wait) instead of two 64-bit shuffles after it;
+//   - k is a template parameter for the k's that matter (19, 21), which turns the variable 64-bit shifts into constants;
+//   - event counters are one packed register, flushed per wave every 256 rounds.
+// G = 8 / 16: groups inside one DPP row.  G = 64: one group per wave, group state in scalar registers.
+// ======================================================================================================================
+template <int D>
+__device__ __forceinline__ uint32_t dpp_row_shr(uint32_t v)
+{
+    // lane l of a 16-lane row reads lane l - D of the same row; lanes without such a source read 0
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x110 + D, 0xf, 0xf, true);
+}
+
+// codes of the row's lanes first..this one, this lane's code in bits 0-1, the lane before in bits 2-3, ...
+__device__ __forceinline__ uint32_t row_scan16(uint32_t code)
+{
+    uint32_t v = code;
+    v |= dpp_row_shr<1>(v) << 2;
+    v |= dpp_row_shr<2>(v) << 4;
+    v |= dpp_row_shr<4>(v) << 8;
+    v |= dpp_row_shr<8>(v) << 16;
+    return v;
+}
+__device__ __forceinline__ uint32_t row_scan4(uint32_t code)
+{
+    uint32_t v = code;
+    v |= dpp_row_shr<1>(v) << 2;
+    v |= dpp_row_shr<2>(v) << 4;
+    return v; // lanes of the row's later groups also carry codes of the group before: the caller keeps 2 * (gl + 1) bits
+}
+__device__ __forceinline__ uint32_t row_scan8(uint32_t code)
+{
+    uint32_t v = code;
+    v |= dpp_row_shr<1>(v) << 2;
+    v |= dpp_row_shr<2>(v) << 4;
+    v |= dpp_row_shr<4>(v) << 8;
+    return v; // lanes 8..15 of a row also carry codes of lanes 0..7: the caller keeps 2 * (gl + 1) bits
+}
+
+template <int G, int KT>
+__global__ __launch_bounds__(256, 7) void one_kernel(PassParams p)
+{
+    static_assert(G == 4 || G == 8 || G == 16 || G == 64, "one_kernel: 4, 8, 16 or 64 lanes per read");
+    const int lane0 = threadIdx.x & 63;
+    int lane = lane0, gl = lane0 & (G - 1), gshift = lane0 & ~(G - 1); // re-derived every round from an opaque copy (see the loop)
+    constexpr uint32_t GM32 = G >= 32 ? 0xffffffffu : ((1u << (G & 31)) - 1u);
+    const int k = KT ? KT : p.k;
+    const uint32_t c = (uint32_t)p.c;
+    const uint64_t mask = kmask(k);
+    uint32_t bcast_addr = (uint32_t)(gshift + G - 1) * 4u; // ds_bpermute address of the group's last lane
+    uint32_t nb2 = 2u * ((uint32_t)gl + 1u);               // bits of this lane's scan value
+    constexpr int WB = G == 4 ? 16 : (G < 32 ? G : 32);          // bases in the look-ahead window
+
+    // group-uniform state
+    uint32_t r = 0, n = 0, cap = 0, i = 0, olen = 0;
+    const uint8_t *in = nullptr;
+    uint8_t *out = nullptr;
+    uint64_t kmer = 0, corr = 0;
+    bool prev = false, have = false;
+    int st = ST_INIT;
+    uint32_t sub = 0, failmask = 0, passmask = 0;
+    uint32_t hop = 0;
+    bool slow = false, was_unres = false, kept_sol = false;
+    typename std::conditional<(G < 32), uint32_t, uint64_t>::type win = 0; // seq[i .. i+WB) at the trigger, 2 bits per base
+    uint32_t steps = 0;
+    // events of this lane since the last flush: rounds | probes << 8 | triggers << 16 | fixes << 24 (flushed every
+    // 255 rounds at most, so no field overflows)
+    uint32_t ev = 0, since_flush = 0;
+
+    auto flush = [&]() {
+        // per-field sums over the wave, then one atomic per counter: every 255 rounds, so it is noise (and keeps the
+        // totals out of the register file of a kernel that sits at its 80-VGPR limit)
+        uint32_t a = ev & 0xffu, b = (ev >> 8) & 0xffu, cc = (ev >> 16) & 0xffu, d = ev >> 24;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            a += __shfl_xor(a, o);
+            b += __shfl_xor(b, o);
+            cc += __shfl_xor(cc, o);
+            d += __shfl_xor(d, o);
+        }
+        if (lane == 0) {
+            if (a)
+                atomicAdd(p.ctrl + CTL_ROUNDS, (unsigned long long)a);
+            if (b)
+                atomicAdd(p.ctrl + CTL_PROBES, (unsigned long long)b);
+            if (cc)
+                atomicAdd(p.ctrl + CTL_TRIGGERS, (unsigned long long)cc);
+            if (d)
+                atomicAdd(p.ctrl + CTL_FIXES, (unsigned long long)d);
+        }
+        ev = 0;
+        since_flush = 0;
+    };
+
+    auto fetch = [&]() {
+        for (;;) {
+            unsigned long long w = 0;
+            if (gl == 0)
+                w = atomicAdd(p.ctrl + CTL_WORK, 1ull);
+            w = __shfl(w, gshift);
+            if (w >= (unsigned long long)p.n_reads) {
+                have = false;
+                return;
+            }
+            have = true;
+            r = (uint32_t)w;
+            const uint64_t o0 = p.offsets[r], o1 = p.offsets[r + 1];
+            if (p.in_staged) {
+                in = p.in + slot_of(o0, r, p.slack);
+                n = p.in_lens[r];
+                if (n == 0xffffffffu) { // poisoned by an earlier pass of this attempt: stays poisoned
+                    if (gl == 0)
+                        p.out_lens[r] = 0xffffffffu;
+                    continue;
+                }
+            } else {
+                in = p.in + o0;
+                n = (uint32_t)(o1 - o0);
+            }
+            const uint64_t s0 = slot_of(o0, r, p.slack), s1 = slot_of(o1, (uint64_t)r + 1, p.slack);
+            out = p.out + s0;
+            cap = (uint32_t)(s1 - s0);
+            st = ST_INIT;
+            i = 0;
+            olen = 0;
+            kmer = 0;
+            prev = false;
+            steps = 0;
+            return;
+        }
+    };
+    auto ld = [&](uint32_t j) -> uint8_t { return in[p.flip ? (n - 1u - j) : j]; };
+    // The read is finished (or given up) at ONE place, the end of the round: every call site of an inlined fetch()
+    // redefines the whole group state, and the compiler pays for each with a block of register copies at the join.
+    int done = 0; // 0 no, 1 finished, 16 + the CTL_* counter of the reason the read was given up
+    auto finish = [&]() { done = 1; };
+    auto give_up = [&](int which) { done = 16 + which; };
+    // this lane's k-mer: `carry` extended by the codes of lanes 0..gl of the group (scan = those codes, 32 bits)
+    auto lane_kmer = [&](uint64_t carry, uint32_t code, uint32_t &scan_out) -> uint64_t {
+        if (G == 4) {
+            const uint32_t v = row_scan4(code) & ((1u << nb2) - 1u);
+            scan_out = v;
+            return ((carry << nb2) | v) & mask;
+        } else if (G == 8) {
+            const uint32_t v = row_scan8(code) & ((1u << nb2) - 1u);
+            scan_out = v;
+            return ((carry << nb2) | v) & mask;
+        } else if (G == 16) {
+            const uint32_t v = row_scan16(code);
+            scan_out = v;
+            return ((carry << nb2) | v) & mask; // nb2 <= 32
+        } else {
+            // 64 lanes = 4 rows: own row's codes + the 16-base words of the two rows before (row 0 / 1: of `carry`)
+            const uint32_t v = row_scan16(code);
+            scan_out = v;
+            const uint32_t clo = (uint32_t)carry, chi = (uint32_t)(carry >> 32);
+            // b1 = full word of the previous row (lane 15 of it); row 0 keeps carry's low word
+            const uint32_t b1 = (uint32_t)__builtin_amdgcn_update_dpp((int)clo, (int)v, 0x142 /* row_bcast:15 */, 0xe, 0xf, false);
+            // b2 = word of the row before that: rows 2, 3 from b1's row_bcast; row 1 = carry low, row 0 = carry high
+            const uint32_t old2 = (lane < 16) ? chi : clo;
+            const uint32_t b2 = (uint32_t)__builtin_amdgcn_update_dpp((int)old2, (int)b1, 0x142, 0xc, 0xf, false);
+            const uint32_t jb = 2u * ((uint32_t)(lane & 15) + 1u);
+            const uint64_t hi = ((uint64_t)b2 << 32) | b1;
+            return ((hi << jb) | v) & mask; // jb <= 32
+        }
+    };
+    // km extended by window bases b0 .. b0+nb-1 (b0 + nb <= WB; the window holds seq[i .. i+WB) at the trigger)
+    auto ext = [&](uint64_t km, uint32_t b0, uint32_t nb) -> uint64_t {
+        const uint64_t bits = (uint64_t)((win >> (2u * ((uint32_t)WB - b0 - nb))) & (decltype(win))((1ull << (2u * nb)) - 1ull));
+        return ((km << (2u * nb)) | bits) & mask;
+    };
+
+    fetch();
+
+    while (__any(have)) {
+        // The compiler hoists every lane constant out of this loop (2*(gl+1), gl-3, (gl==0)<<16, ...) and then, at the
+        // 80-register limit, spills some of them to scratch and reloads them in the SCAN path.  Deriving them from an
+        // opaque copy of the lane id costs four instructions per round and keeps the register file for the state.
+        lane = lane0;
+        asm volatile("" : "+v"(lane));
+        gl = lane & (G - 1);
+        gshift = lane & ~(G - 1);
+        bcast_addr = (uint32_t)(lane | (G - 1)) * 4u;
+        nb2 = 2u * ((uint32_t)gl + 1u);
+        bool do_probe = false;
+        uint64_t pk = 0;
+        uint8_t ch = 0;
+        uint32_t sc_s = 0, scan = 0, gwin = 0;
+        bool sc_active = false;
+
+        // ---------------- phase 1 -----------------------------------------------------------------------------------
+        if (have) {
+            ev += (gl == 0) ? 1u : 0u;
+            if (st == ST_SCAN) {
+                const uint32_t pos = i + (uint32_t)gl;
+                const bool valid = pos < n;
+                ch = valid ? ld(pos) : (uint8_t)0;
+                pk = lane_kmer(kmer, (uint32_t)nuc2bit(ch), scan);
+                do_probe = valid;
+                if (G <= 16) // all G codes of the group, for the k-mer the group leaves this round with
+                    gwin = (uint32_t)__builtin_amdgcn_ds_bpermute((int)bcast_addr, (int)scan);
+            } else if (st == ST_INIT) {
+                if (n < (uint32_t)k) {
+                    for (uint32_t j = gl; j < n; j += G) // mod.rs:56-58
+                        out[j] = ld(j);
+                    olen = n;
+                } else {
+                    uint64_t km = 0;
+                    for (int j = 0; j < k; j++)
+                        km = (km << 2) | nuc2bit(ld((uint32_t)j));
+                    kmer = km;
+                    for (uint32_t j = gl; j < (uint32_t)k; j += G)
+                        out[j] = ld(j);
+                    olen = (uint32_t)k;
+                    i = (uint32_t)k;
+                    do_probe = (gl == 0);
+                    pk = kmer;
+                }
+            } else if (st == ST_ALTS) {
+                do_probe = gl < 4 && (uint64_t)gl != (kmer & 3ull); // the read's own base is the trigger k-mer: known non-solid
+                pk = (kmer & ~3ull) | (uint64_t)gl;                  // add_nuc(kmer >> 2, gl)
+                // the bases the scenarios will look at, fetched once: seq[i .. i+WB)
+                if (G == 4) {
+                    // four bases per lane: one (unaligned) dword, the four codes gathered into a byte by one multiply
+                    const uint32_t w4 = i + 4u * (uint32_t)gl;
+                    uint32_t raw = 0;
+                    if (w4 + 4u <= n) {
+                        const uint8_t *q = p.flip ? in + (n - 4u - w4) : in + w4;
+                        __builtin_memcpy(&raw, q, 4);
+                        if (p.flip)
+                            raw = __builtin_bswap32(raw);
+                    } else {
+                        for (uint32_t t = 0; t < 4u && w4 + t < n; t++)
+                            raw |= (uint32_t)ld(w4 + t) << (8u * t);
+                    }
+                    // bytes b0..b3 (b0 = first base) -> b0<<6 | b1<<4 | b2<<2 | b3: the four products land in bits 24-31, every
+                    // other partial product below bit 24 or beyond bit 31, none overlapping
+                    uint32_t v = ((((raw >> 1) & 0x03030303u) * 0x40100401u) >> 24);
+                    v |= dpp_row_shr<1>(v) << 8;
+                    v |= dpp_row_shr<2>(v) << 16;
+                    if (gl != 3)
+                        v &= (1u << (8u * ((uint32_t)gl + 1u))) - 1u;
+                    win = (uint32_t)__builtin_amdgcn_ds_bpermute((int)bcast_addr, (int)v);
+                }
+                const uint32_t wp = i + (uint32_t)gl;
+                const uint32_t cd = (G != 4 && gl < WB && wp < n) ? (uint32_t)nuc2bit(ld(wp)) : 0u;
+                if (G == 4) {
+                } else if (G == 8) {
+                    const uint32_t v = row_scan8(cd) & ((1u << nb2) - 1u);
+                    win = (uint32_t)__builtin_amdgcn_ds_bpermute((int)bcast_addr, (int)v);
+                } else if (G == 16) {
+                    win = (uint32_t)__builtin_amdgcn_ds_bpermute((int)bcast_addr, (int)row_scan16(cd));
+                } else {
+                    // rows 0 and 1 of the wave hold the 32 window bases
+                    const uint32_t v = row_scan16(cd);
+                    const uint32_t w0 = (uint32_t)__builtin_amdgcn_readlane((int)v, 15), w1 = (uint32_t)__builtin_amdgcn_readlane((int)v, 31);
+                    win = ((uint64_t)w0 << 32) | w1;
+                }
+            } else if (st == ST_SCEN) {
+                const uint32_t width = scen_width(sub, c, G, 0u, failmask);
+                const uint32_t e = (uint32_t)gl;
+                const uint32_t alive = ~failmask & 7u;
+                // ord = e / width, e % width -- at most three scenarios, so two compares do the division
+                const uint32_t ord = (e >= width ? 1u : 0u) + (e >= 2u * width ? 1u : 0u);
+                sc_active = e < 3u * width && ord < (uint32_t)__popc(alive);
+                const uint32_t a1 = alive & (alive - 1u);
+                sc_s = !sc_active ? 0u : (ord == 0u ? (uint32_t)__ffs(alive) - 1u : (ord == 1u ? (uint32_t)__ffs(a1) - 1u : 2u));
+                const uint32_t j = sub + (sc_active ? e - ord * width : 0u);
+                const uint32_t off = 2u - sc_s; // I:2 S:1 D:0 (one.rs:57-63)
+                if (sc_active) {
+                    if (c + 3u <= (uint32_t)WB) {
+                        pk = ext(corr, off, j + 1u);
+                    } else {
+                        pk = corr;
+                        for (uint32_t q = 0; q <= j; q++)
+                            pk = add_nuc(pk, nuc2bit(ld(i + off + q)), mask);
+                    }
+                    do_probe = true;
+                }
+            } else { // ST_MORE
+                if (gl < 3 && ((passmask >> gl) & 1u)) {
+                    const uint32_t off = 2u - (uint32_t)gl;
+                    const uint32_t rem = n - i;
+                    if (rem > c + off + 1u) { // exist/mod.rs:54
+                        if (c + 3u <= (uint32_t)WB) {
+                            pk = ext(corr, off, c + 1u);
+                        } else {
+                            pk = corr;
+                            for (uint32_t q = 0; q <= c; q++)
+                                pk = add_nuc(pk, nuc2bit(ld(i + off + q)), mask);
+                        }
+                        do_probe = true;
+                    }
+                }
+            }
+            if (++steps > (1u << 24) + 64u * n) // runaway guard, as in correct_kernel
+                do_probe = false;
+        }
+
+        // ---------------- phase 2: one probe per lane -----------------------------------------------------------------
+        bool sol = false, retry = false;
+        if (p.idx.lines) {
+            bool unres = false;
+            if (do_probe) {
+                if (!slow) {
+                    const int pr = index_probe(p.idx, pk, k);
+                    sol = pr == 1;
+                    unres = pr == 2;
+                    ev += 1u << 8;
+                } else if (was_unres) {
+                    if (p.bits) {
+                        sol = probe(p.bits, pk, k);
+                    } else {
+                        const int pr = index_probe(p.idx, pk, k, hop);
+                        sol = pr == 1;
+                        unres = pr == 2;
+                    }
+                    ev += 1u << 8;
+                } else {
+                    sol = kept_sol;
+                }
+            }
+            const uint64_t ub = __ballot(unres);
+            retry = G == 64 ? ub != 0ull : (((uint32_t)(ub >> gshift) & GM32) != 0u);
+            hop = retry ? hop + 1u : 0u;
+            slow = retry;
+            was_unres = unres;
+            kept_sol = sol;
+        } else if (do_probe) {
+            sol = probe(p.bits, pk, k);
+            ev += 1u << 8;
+        }
+        const uint64_t ball = __ballot(sol);
+
+        // ---------------- phase 3 -------------------------------------------------------------------------------------
+        if (have && !retry) {
+            bool fail = false;
+            int apply_s = -1;
+            if (st == ST_SCAN) {
+                const uint32_t left = n - i;
+                const uint32_t nvalid = left < (uint32_t)G ? left : (uint32_t)G;
+                uint32_t nacc;
+                bool trg;
+                bool last_sol;
+                if (G == 64) {
+                    const uint64_t vmask = (nvalid >= 64) ? ~0ull : ((1ull << nvalid) - 1ull);
+                    const uint64_t trig = ~ball & ((ball << 1) | (prev ? 1ull : 0ull)) & vmask; // mod.rs:73
+                    trg = trig != 0ull;
+                    nacc = trg ? (uint32_t)__builtin_ctzll(trig) : nvalid;
+                    last_sol = nacc ? ((ball >> (nacc - 1u)) & 1ull) : prev;
+                } else {
+                    const uint32_t gm = (uint32_t)(ball >> gshift) & GM32;
+                    const uint32_t vmask = (1u << nvalid) - 1u; // G <= 16
+                    const uint32_t trig = ~gm & ((gm << 1) | (prev ? 1u : 0u)) & vmask;
+                    trg = trig != 0u;
+                    nacc = trg ? (uint32_t)__builtin_ctz(trig) : nvalid;
+                    last_sol = nacc ? ((gm >> (nacc - 1u)) & 1u) : prev;
+                }
+                if (olen + nacc + 1u > cap) {
+                    give_up(CTL_OVERFLOW);
+                } else {
+                    if ((uint32_t)gl < nacc)
+                        out[olen + (uint32_t)gl] = ch; // mod.rs:100
+                    olen += nacc;
+                    i += nacc;
+                    // the k-mer the group goes on with: after the accepted bases, plus the trigger base if there is one
+                    const uint32_t ncodes = nacc + (trg ? 1u : 0u);
+                    if (G == 64) {
+                        const int src = (int)ncodes - 1; // ncodes >= 1: nvalid >= 1 in SCAN
+                        const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)pk, src);
+                        const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(pk >> 32), src);
+                        kmer = ((uint64_t)hi << 32) | lo;
+                    } else {
+                        kmer = ((kmer << (2u * ncodes)) | (uint64_t)(gwin >> (2u * ((uint32_t)G - ncodes)))) & mask;
+                    }
+                    if (trg) {
+                        ev += (gl == 0) ? (1u << 16) : 0u;
+                        st = ST_ALTS;
+                    } else {
+                        prev = last_sol; // mod.rs:99
+                        if (i >= n)
+                            finish();
+                    }
+                }
+            } else if (st == ST_INIT) {
+                if (n < (uint32_t)k) {
+                    finish();
+                } else {
+                    prev = (ball >> gshift) & 1ull; // mod.rs:67
+                    if (i >= n)
+                        finish();
+                    else
+                        st = ST_SCAN;
+                }
+            } else if (st == ST_ALTS) {
+                const uint32_t am = (uint32_t)(ball >> gshift) & 0xfu;
+                if (__popc(am) != 1) {
+                    fail = true; // exist/mod.rs:123-126
+                } else {
+                    corr = (kmer & ~3ull) | (uint64_t)(__ffs(am) - 1);
+                    const uint32_t rem = n - i;
+                    failmask = 0;
+                    for (uint32_t s = 0; s < 3; s++)
+                        if ((2u - s) + c > rem) // exist/mod.rs:27-29
+                            failmask |= 1u << s;
+                    if (failmask == 7u) {
+                        fail = true;
+                    } else if (c == 0u) {
+                        passmask = 7u & ~failmask;
+                        if (__popc(passmask) == 1)
+                            apply_s = __ffs(passmask) - 1;
+                        else
+                            st = ST_MORE;
+                    } else {
+                        sub = 0;
+                        st = ST_SCEN;
+                    }
+                }
+            } else if (st == ST_SCEN) {
+                const bool bad = sc_active && !sol;
+                const uint32_t w_used = scen_width(sub, c, G, 0u, failmask);
+                // lanes [ord*w, (ord+1)*w) worked for the ord-th surviving scenario
+                const uint64_t bb = __ballot(bad);
+                const uint32_t badm = G == 64 ? 0u : ((uint32_t)(bb >> gshift) & GM32);
+                uint32_t alive = ~failmask & 7u, ord = 0;
+                for (uint32_t s = 0; s < 3; s++)
+                    if ((alive >> s) & 1u) {
+                        bool any;
+                        if (G == 64) {
+                            const uint64_t wm = (w_used >= 64u ? ~0ull : ((1ull << w_used) - 1ull)) << (ord * w_used);
+                            any = (bb & wm) != 0ull;
+                        } else {
+                            any = ((badm >> (ord * w_used)) & ((1u << w_used) - 1u)) != 0u;
+                        }
+                        if (any)
+                            failmask |= 1u << s;
+                        ord++;
+                    }
+                sub += w_used;
+                if (failmask == 7u) {
+                    fail = true; // exist/mod.rs:132-134
+                } else if (sub >= c) {
+                    passmask = 7u & ~failmask;
+                    if (__popc(passmask) == 1)
+                        apply_s = __ffs(passmask) - 1; // exist/mod.rs:135-137
+                    else
+                        st = ST_MORE;
+                }
+            } else { // ST_MORE
+                const uint32_t keep = (uint32_t)(ball >> gshift) & 7u & passmask;
+                if (__popc(keep) == 1)
+                    apply_s = __ffs(keep) - 1; // exist/mod.rs:143-144
+                else
+                    fail = true;
+            }
+            if (have && steps > (1u << 24) + 64u * n) {
+                fail = false;
+                apply_s = -1;
+                give_up(CTL_NONTERM);
+            }
+            if (fail) {
+                // mod.rs:91-96: the trigger base is copied through
+                if (olen + 2u > cap) {
+                    give_up(CTL_OVERFLOW);
+                } else {
+                    if (gl == 0)
+                        out[olen] = ld(i);
+                    olen += 1;
+                    i += 1;
+                    prev = false;
+                    if (i >= n)
+                        finish();
+                    else
+                        st = ST_SCAN;
+                }
+            } else if (apply_s >= 0) {
+                // mod.rs:75-89 with one.rs:65-71
+                if (olen + 2u > cap) {
+                    give_up(CTL_OVERFLOW);
+                } else {
+                    if (gl == 0)
+                        out[olen] = bit2nuc(corr & 3ull);
+                    olen += 1;
+                    kmer = corr;
+                    prev = true;
+                    const uint32_t off = 2u - (uint32_t)apply_s;
+                    i += off;
+                    ev += (gl == 0) ? (1u << 24) : 0u;
+                    // the c look-ahead k-mers of the winning scenario ARE the next c scan k-mers, all found solid: the
+                    // reference's loop would copy these bases with previous = true (mod.rs:99-102)
+                    if (c > 0u && c + 3u <= (uint32_t)WB && olen + c + 1u <= cap) {
+                        for (uint32_t q = (uint32_t)gl; q < c; q += (uint32_t)G)
+                            out[olen + q] = ld(i + q);
+                        kmer = ext(kmer, off, c);
+                        olen += c;
+                        i += c;
+                    }
+                    if (i >= n)
+                        finish();
+                    else
+                        st = ST_SCAN;
+                }
+            }
+        }
+        if (done) {
+            if (gl == 0) {
+                p.out_lens[r] = done == 1 ? olen : 0xffffffffu;
+                if (done != 1)
+                    atomicAdd(p.ctrl + (done - 16), 1ull);
+            }
+            done = 0;
+            fetch();
+        }
+        if (++since_flush == 255u)
+            flush();
+    }
+    flush();
+}
+
 // one workgroup per read (grid-stride): staged slot -> compact output, reversing if needed
 __global__ __launch_bounds__(256) void compact_kernel(const uint8_t *__restrict__ stage, const uint32_t *__restrict__ lens,
                                                       const uint64_t *__restrict__ offsets, uint32_t n_reads,
@@ -1283,16 +1813,32 @@ int group_width(bool reverse_pass = false, bool indexed = false, uint32_t n_read
         while (g < 64 && (uint64_t)n_reads * (uint64_t)g * 2u <= RESIDENT_LANES)
             g *= 2;
     }
-    return (g == 8 || g == 16 || g == 32 || g == 64) ? g : dflt;
+    return (g == 4 || g == 8 || g == 16 || g == 32 || g == 64) ? g : dflt;
 }
 
 constexpr uint32_t MAX_BLOCKS = 256u * 8u;
 
-uint32_t pass_blocks(uint32_t n_reads, int G)
+uint32_t pass_blocks(uint32_t n_reads, int G, bool balanced = false)
 {
     const uint32_t groups_per_block = 256u / (uint32_t)G;
     // persistent-ish grid: enough groups to fill the chip, reads pulled from a work counter
     uint64_t want = ((uint64_t)n_reads + groups_per_block - 1) / groups_per_block;
+    if (balanced) {
+        // Reads of a batch take about the same time, and a wave costs the same instructions whether 8 of its groups
+        // are busy or 3: 100 000 reads over 49 152 resident 8-lane groups is two reads each and a third for a few,
+        // i.e. a last third of the kernel run by mostly idle waves.  Fewer groups with the same whole number of reads
+        // each end together.
+        // Measured (profiles/r2_one_kernel_ab.txt): NOT a win -- 4 168 waves instead of 8 192 leave the SIMDs waiting on
+        // memory (VALU busy 65 % instead of 79 %, 32.6 ms against 27.2); kept behind BRX_BALANCE=1 for the record.
+        static const bool on = [] { const char *e = getenv("BRX_BALANCE"); return e && *e == '1'; }();
+        const uint64_t resident_blocks = 256ull * 7; // CUs x (waves per SIMD x 4 SIMDs / 4 waves per block): one_kernel runs 7 per SIMD
+        const uint64_t resident_groups = resident_blocks * groups_per_block;
+        if (on && (uint64_t)n_reads > resident_groups) {
+            const uint64_t per_group = ((uint64_t)n_reads + resident_groups - 1) / resident_groups;
+            const uint64_t groups = ((uint64_t)n_reads + per_group - 1) / per_group;
+            want = (groups + groups_per_block - 1) / groups_per_block;
+        }
+    }
     if (want > MAX_BLOCKS)
         want = MAX_BLOCKS;
     if (want < 1)
@@ -1300,15 +1846,42 @@ uint32_t pass_blocks(uint32_t n_reads, int G)
     return (uint32_t)want;
 }
 
+template <int G>
+void launch_one(const PassParams &p, uint32_t blocks, hipStream_t s)
+{
+    if (p.k == 19)
+        one_kernel<G, 19><<<blocks, 256, 0, s>>>(p);
+    else if (p.k == 21)
+        one_kernel<G, 21><<<blocks, 256, 0, s>>>(p);
+    else
+        one_kernel<G, 0><<<blocks, 256, 0, s>>>(p);
+}
+
 template <int M>
 int launch_method(const PassParams &p, int G, uint32_t blocks, size_t lds, hipStream_t s)
 {
+    if (M == BRX_ONE && G != 32) {
+        // (4-lane groups exist in this form only)
+        // BRX_ONE_V1=1: the first form of the kernel (A/B runs; results are identical)
+        static const bool v1 = [] { const char *e = getenv("BRX_ONE_V1"); return e && *e == '1'; }();
+        if (!v1) {
+            if (G == 4)
+                launch_one<4>(p, blocks, s);
+            else if (G == 8)
+                launch_one<8>(p, blocks, s);
+            else if (G == 16)
+                launch_one<16>(p, blocks, s);
+            else
+                launch_one<64>(p, blocks, s);
+            return BRX_OK;
+        }
+    }
     if (lds > 64 * 1024) {
         const void *fn = G == 16 ? (const void *)correct_kernel<16, M>
                        : G == 32 ? (const void *)correct_kernel<32, M> : (const void *)correct_kernel<64, M>;
         BRX_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
-    if (G == 8 && M == BRX_ONE)
+    if (G <= 8 && M == BRX_ONE)
         correct_kernel<8, BRX_ONE><<<blocks, 256, lds, s>>>(p);
     else if (G <= 16)
         correct_kernel<16, M><<<blocks, 256, lds, s>>>(p);
@@ -1352,7 +1925,7 @@ int launch_pass(PassParams p, const brx_method_t &md, int G, hipStream_t s)
         }
         lds = (size_t)(256 / G) * p.g_lds_bytes;
     }
-    const uint32_t blocks = pass_blocks(p.n_reads, G);
+    const uint32_t blocks = pass_blocks(p.n_reads, G, method == BRX_ONE);
     KernelTimer t(names[method], s);
     switch (method) {
     case BRX_ONE: BRX_TRY(launch_method<BRX_ONE>(p, G, blocks, lds, s)); break;

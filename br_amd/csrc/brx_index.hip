@@ -139,7 +139,7 @@ bool index_wanted(int k)
 int index_auto_m(int k, uint64_t n_keys)
 {
     int m = 3;
-    while (m < IDX_MAX_M && (1ull << (2 * m - 1)) < 16ull * n_keys)
+    while (m < IDX_AUTO_MAX_M && (1ull << (2 * m - 1)) < 16ull * n_keys)
         m += 2;
     if (m > k - 2)
         m = k - 2;
@@ -160,8 +160,8 @@ static int index_build_locked(brx_set *set, const uint64_t *d_keys, uint64_t n, 
         m = env_int("BRX_INDEX_M", 0);
     if (m <= 0)
         m = index_auto_m(k, n);
-    if (!(m & 1) || m < 3 || m > IDX_MAX_M || k - m + 1 < 2) {
-        set_error("probe index: minimizer length %d must be odd, 3..%d and shorter than the %d-mer", m, IDX_MAX_M, k);
+    if ((!(m & 1) && m != 16) || m < 3 || m > IDX_MAX_M || k - m + 1 < 2) {
+        set_error("probe index: minimizer length %d must be odd (or 16), 3..%d and shorter than the %d-mer", m, IDX_MAX_M, k);
         return BRX_ERR_ARG;
     }
     if (log_lines <= 0)
@@ -277,7 +277,7 @@ int index_insert_reads(brx_set *set, const uint8_t *d_bases, const uint64_t *d_o
         int m = env_int("BRX_INDEX_M", 0);
         if (m <= 0)
             m = index_auto_m(k, need);
-        if (!(m & 1) || m < 3 || m > IDX_MAX_M || m > k - 1) {
+        if ((!(m & 1) && m != 16) || m < 3 || m > IDX_MAX_M || m > k - 1) {
             set_error("probe index: bad minimizer length %d for k=%d", m, k);
             return BRX_ERR_ARG;
         }

@@ -23,8 +23,16 @@ constexpr uint64_t IDX_OVERFLOW = 1ull << 63;
 // bits 32..62 of a line's header: a 31-bit signature of the keys that did not fit THEIR HOME line (the line their
 // minimizer addresses).  A probe that finds its home line flagged but its own signature bit clear is a definite
 // "absent" -- without it every probe of a flagged line, present or not, costs its group a second round.
-__host__ __device__ inline uint64_t idx_sig_bit(uint64_t key) { return 1ull << (32u + (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> 59) % 31u); }
-constexpr int IDX_MAX_M = 15; // a canonical m-mer must fit 30 bits (32-bit window arithmetic)
+// (32-bit multiply of the key's low word, top 5 bits, 31 folded onto 30: five instructions in the probe instead of a
+// 64-bit multiply and a modulo)
+__host__ __device__ inline uint32_t idx_sig_index(uint64_t key)
+{
+    const uint32_t t = ((uint32_t)key * 0x9E3779B1u) >> 27;
+    return t > 30u ? 30u : t;
+}
+__host__ __device__ inline uint64_t idx_sig_bit(uint64_t key) { return 1ull << (32u + idx_sig_index(key)); }
+constexpr int IDX_MAX_M = 16; // a canonical m-mer must fit 32 bits (32-bit window arithmetic); 16 needs no masking
+constexpr int IDX_AUTO_MAX_M = 15; // what index_auto_m picks by itself (odd lengths; BRX_INDEX_M / the ABI may ask for 16)
 
 struct IdxView {
     const uint64_t *lines; // nullptr: no index, probe the bitset
@@ -57,7 +65,7 @@ __device__ __forceinline__ uint32_t minimizer_hash_w(uint64_t fwd, uint64_t rc, 
 
 __device__ __forceinline__ uint32_t minimizer_of(uint64_t fwd, uint64_t rc, uint32_t m, uint32_t w)
 {
-    const uint32_t mm = (1u << (2u * m)) - 1u;
+    const uint32_t mm = m >= 16u ? 0xffffffffu : (1u << (2u * m)) - 1u;
     switch (w) { // wave-uniform
     case 2: return minimizer_hash_w<2>(fwd, rc, mm);
     case 3: return minimizer_hash_w<3>(fwd, rc, mm);
@@ -108,7 +116,8 @@ __device__ __forceinline__ int index_probe(const IdxView &v, uint64_t fwd, int k
     const bool found = (q0.x == key) | (q0.y == key) | (q1.x == key) | (q1.y == key) | (q2.x == key) | (q2.y == key) | (q3.x == key);
     // home line (hop 0): go on only if one of the keys it turned away had this key's signature; further down a
     // chain only the flag can tell
-    const bool more = (q3.y & IDX_OVERFLOW) && (hop != 0u || (q3.y & idx_sig_bit(key)));
+    const uint32_t hdr_hi = (uint32_t)(q3.y >> 32); // bit 31 = overflowed, bits 0..30 = signature of the keys turned away
+    const bool more = (hdr_hi >> 31) && (hop != 0u || ((hdr_hi >> idx_sig_index(key)) & 1u));
     return found ? 1 : (more ? 2 : 0);
 }
 // find-or-insert of one k-mer into a chained table (sparse sets filled k-mer by k-mer, `br large-kmer`): true if the
