@@ -456,32 +456,14 @@ __global__ __launch_bounds__(256, (M == BRX_ONE ? (G == 64 ? 7 : 6) : (M == BRX_
     };
     // logical base j of the current read (the reverse pass reads the buffer back to front)
     auto ld = [&](uint32_t j) -> uint8_t { return in[p.flip ? (n - 1u - j) : j]; };
-    auto finish = [&]() {
-        if (gl == 0)
-            p.out_lens[r] = olen;
-        fetch();
-    };
-    auto overflow = [&]() {
-        if (gl == 0) {
-            p.out_lens[r] = 0xffffffffu;
-            atomicAdd(p.ctrl + CTL_OVERFLOW, 1ull);
-        }
-        fetch();
-    };
-    auto nonterminating = [&]() {
-        if (gl == 0) {
-            p.out_lens[r] = 0xffffffffu;
-            atomicAdd(p.ctrl + CTL_NONTERM, 1ull);
-        }
-        fetch();
-    };
-    auto path_overflow = [&]() {
-        if (gl == 0) {
-            p.out_lens[r] = 0xffffffffu;
-            atomicAdd(p.ctrl + CTL_PATHOVF, 1ull);
-        }
-        fetch();
-    };
+    // A read is finished (or given up) at ONE place, the end of the round: every call site of an inlined fetch() redefines
+    // the whole group state and costs a block of register copies at the join (one_kernel: 7 000 -> 4 900 lines of ISA)
+    int done = 0; // 0 no, 1 finished, 16 + the CTL_* counter of the reason the read was given up
+    auto end_read = [&](int how) { done = how; };
+    auto finish = [&]() { end_read(1); };
+    auto overflow = [&]() { end_read(16 + CTL_OVERFLOW); };
+    auto nonterminating = [&]() { end_read(16 + CTL_NONTERM); };
+    auto path_overflow = [&]() { end_read(16 + CTL_PATHOVF); };
     // k-mer of this lane after appending the 2-bit codes of lanes 0..gl of the group to `carry`
     auto lane_kmer = [&](uint64_t carry, uint64_t code) -> uint64_t {
         uint64_t val = code;
@@ -1102,7 +1084,7 @@ __global__ __launch_bounds__(256, (M == BRX_ONE ? (G == 64 ? 7 : 6) : (M == BRX_
                     }
                 }
             }
-            if (have && steps > (1u << 24) + 64u * n) {
+            if (have && !done && steps > (1u << 24) + 64u * n) {
                 fail = false;
                 apply_s = apply_t = -1;
                 apply_path = false;
@@ -1194,6 +1176,15 @@ __global__ __launch_bounds__(256, (M == BRX_ONE ? (G == 64 ? 7 : 6) : (M == BRX_
                         st = ST_SCAN;
                 }
             }
+        }
+        if (done) {
+            if (gl == 0) {
+                p.out_lens[r] = done == 1 ? olen : 0xffffffffu;
+                if (done != 1)
+                    atomicAdd(p.ctrl + (done - 16), 1ull);
+            }
+            done = 0;
+            fetch();
         }
         // end of the round, every lane back together: count the events
         n_rounds += (uint32_t)__builtin_popcountll(__ballot(ev & EV_ROUND));
