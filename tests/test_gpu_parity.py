@@ -664,13 +664,14 @@ def test_cli_solid_fastq_and_csv(tmp_path, golden_dir, raw_reads):
     assert [s21.get(x) for x in probe] == [om.get(x) for x in probe]
 
 
-@pytest.mark.parametrize("k", [13, 15, 19])
+@pytest.mark.parametrize("k", [13, 15, 19, 21])
 def test_two_rank_exchange_on_one_gpu(tmp_path, raw_reads, k):
     """SetExchange.build_partitioned with world_size 2 for real: two processes share the card and talk over gloo
     (tests/dist_gpu_worker.py); each counts its half of the reads, the keys go to their owners, the solid lists come
     back, and each rank corrects its own shard against the set of ALL reads.  k = 13: bit vector + OR of the other
     rank's list; k = 15: no bit vector at finish time, the probe index is built from both ranks' lists; k = 19: the
-    owner's finish is the LDS hash-count over its half of the digit range."""
+    owner's finish is the LDS hash-count over its half of the digit range; k = 21 (BASELINE configs[4]'s k): sparse sets,
+    four radix levels, the chained index built from both ranks' lists IS the set."""
     import pickle
     import subprocess
     import sys
