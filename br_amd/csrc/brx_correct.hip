@@ -1739,8 +1739,15 @@ __global__ __launch_bounds__(256) void compact_kernel(const uint8_t *__restrict_
                                                       uint8_t *__restrict__ out)
 {
     for (uint32_t r = blockIdx.x; r < n_reads; r += gridDim.x) {
-        const uint8_t *src = stage + slot_of(offsets[r], r, slack);
-        const uint32_t n = lens[r];
+        const uint64_t s0 = slot_of(offsets[r], r, slack);
+        const uint8_t *src = stage + s0;
+        uint32_t n = lens[r];
+        {   // a read redone outside the batch that does not fit its slot has its length here but its bytes elsewhere (they
+            // are copied over this read's place afterwards): copy no more than the slot holds
+            const uint64_t slot = slot_of(offsets[r + 1], (uint64_t)r + 1, slack) - s0;
+            if ((uint64_t)n > slot)
+                n = (uint32_t)slot;
+        }
         uint8_t *dst = out + out_offsets[r];
         // bytes up to the first 16-byte boundary of dst, then 16 bytes per lane (unaligned load, byte order reversed
         // in registers when the staged read is stored back to front, aligned store), then the tail
@@ -1991,20 +1998,27 @@ int brx_chain_new(const brx_set_t *set, const brx_method_t *methods, uint32_t n_
     return BRX_OK;
 }
 
-// A handful of reads whose graph walk outgrew the visited list (GapSize at BASELINE configs[4]'s per-GPU share: 18
-// of 625 000) should not cost the whole batch a second run.  Everything else of the batch is final and sits in its
-// own slot of the last staging buffer, so the poisoned reads are taken out as a small batch of their own, corrected
-// by a second chain with a longer list (same set, methods and direction rule; all on the GPU), and written back into
-// their slots.  BRX_OK: lens / slots patched, the batch is complete.  BRX_ERR_UNSUPPORTED: not applicable (too many
-// reads, or a corrected read does not fit its slot) -- the caller redoes the whole batch as before.
+// A handful of reads that outgrew their workspace -- a graph walk longer than the visited list (GapSize at BASELINE
+// configs[4]'s per-GPU share: 18 of 625 000) or a correction that grows the read beyond its output slot -- should not
+// cost the whole batch a second run.  Everything else of the batch is final and sits in its own slot of the last
+// staging buffer, so the poisoned reads are taken out as a small batch of their own and corrected by a second chain
+// with a longer list / more slack (same set, methods and direction rule; all on the GPU).  A redone read that fits its
+// slot is written back into it; one that does not goes to `side` and is copied over its place in the compact output
+// after the compaction (its final length is entered in `lens`, so every other read lands where it should).
+// BRX_OK: lens / slots patched, the batch is complete.  BRX_ERR_UNSUPPORTED: not applicable (too many reads) -- the
+// caller redoes the whole batch with a larger workspace as before.
+struct SideRead {
+    uint32_t r;
+    std::vector<uint8_t> bytes;
+};
 static uint32_t redo_max_reads()
 {
     const char *e = getenv("BRX_REDO_MAX"); // tests: 0 = never (read on every use: only overflowing batches get here)
     return e ? (uint32_t)atoi(e) : 4096u;
 }
-static int redo_walk_overflows(brx_chain *ch, const uint8_t *d_bases, const uint64_t *d_offsets, uint32_t n_reads,
-                               uint8_t *d_stage, uint32_t *d_lens, int stage_reversed, uint32_t slack, uint32_t maxpath,
-                               hipStream_t s)
+static int redo_poisoned_reads(brx_chain *ch, const uint8_t *d_bases, const uint64_t *d_offsets, uint32_t n_reads,
+                               uint8_t *d_stage, uint32_t *d_lens, int stage_reversed, uint32_t slack, uint32_t sub_slack,
+                               uint32_t maxpath, std::vector<SideRead> &side, hipStream_t s)
 {
     if (ch->is_sub)
         return BRX_ERR_UNSUPPORTED;
@@ -2038,6 +2052,8 @@ static int redo_walk_overflows(brx_chain *ch, const uint8_t *d_bases, const uint
     }
     if (ch->sub->maxpath_seen < maxpath)
         ch->sub->maxpath_seen = maxpath;
+    if (ch->sub->slack_seen < sub_slack)
+        ch->sub->slack_seen = sub_slack;
     uint8_t *ob = nullptr;
     uint64_t *oo = nullptr;
     BRX_TRY(brx_chain_correct_batch(ch->sub, mb.data(), moff.data(), (uint32_t)ids.size(), &ob, &oo));
@@ -2047,11 +2063,21 @@ static int redo_walk_overflows(brx_chain *ch, const uint8_t *d_bases, const uint
         const uint32_t r = ids[j];
         const uint64_t s0 = slot_of(offs[r], r, slack), s1 = slot_of(offs[r + 1], (uint64_t)r + 1, slack);
         const uint64_t len = oo[j + 1] - oo[j];
-        if (len + 1 > s1 - s0 || len >= 0xffffffffull) {
-            st = BRX_ERR_UNSUPPORTED; // the corrected read does not fit its slot: the whole batch, with more slack
+        if (len >= 0xffffffffull) {
+            st = BRX_ERR_UNSUPPORTED;
             break;
         }
         const uint8_t *src = ob + oo[j];
+        if (len + 1 > s1 - s0) {
+            // does not fit its slot: keep the bytes aside (forward order), enter the length, patch after compaction
+            side.push_back(SideRead{r, std::vector<uint8_t>(src, src + len)});
+            const uint32_t l32s = (uint32_t)len;
+            if (hipMemcpy(d_lens + r, &l32s, 4, hipMemcpyHostToDevice) != hipSuccess) {
+                set_error("redo of poisoned reads: length patch failed");
+                st = BRX_ERR_HIP;
+            }
+            continue;
+        }
         if (stage_reversed) { // the last pass stored its reads back to front
             rev.assign(src, src + len);
             std::reverse(rev.begin(), rev.end());
@@ -2062,7 +2088,7 @@ static int redo_walk_overflows(brx_chain *ch, const uint8_t *d_bases, const uint
         if (e == hipSuccess)
             e = hipMemcpy(d_lens + r, &l32, 4, hipMemcpyHostToDevice);
         if (e != hipSuccess) {
-            set_error("redo of walk-list overflows: %s", hipGetErrorString(e));
+            set_error("redo of poisoned reads: %s", hipGetErrorString(e));
             st = BRX_ERR_HIP;
         }
     }
@@ -2126,6 +2152,7 @@ static int correct_batch_device_locked(brx_chain_t *ch, const uint8_t *d_bases, 
     const int n_dirs = ch->two_side ? 1 : 2;
     const int n_methods = (int)ch->methods.size();
     uint64_t stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    std::vector<SideRead> side; // redone reads that do not fit their staging slot (redo_poisoned_reads)
     const int G = group_width(false, idx.lines != nullptr, n_reads); // forward width (8 exists for One only, else 16)
     bool needs_path = false;
     for (int m = 0; m < n_methods; m++)
@@ -2230,9 +2257,12 @@ static int correct_batch_device_locked(brx_chain_t *ch, const uint8_t *d_bases, 
             stats[5] += ch->h_ctrl[CTL_OVERFLOW]; // reads that outgrew their slot / walks that outgrew the list,
             stats[6] += ch->h_ctrl[CTL_PATHOVF];  // summed over the attempts that were thrown away or patched
             bool patched = false;
-            if (ch->h_ctrl[CTL_OVERFLOW] == 0 && ch->h_ctrl[CTL_PATHOVF] <= redo_max_reads()) {
-                const int rst = redo_walk_overflows(ch, d_bases, d_offsets, n_reads, const_cast<uint8_t *>(cur),
-                                                    const_cast<uint32_t *>(cur_lens), cur_rev, slack, maxpath * 8u, s);
+            if (ch->h_ctrl[CTL_OVERFLOW] + ch->h_ctrl[CTL_PATHOVF] <= redo_max_reads()) {
+                side.clear();
+                const int rst = redo_poisoned_reads(ch, d_bases, d_offsets, n_reads, const_cast<uint8_t *>(cur),
+                                                    const_cast<uint32_t *>(cur_lens), cur_rev, slack,
+                                                    ch->h_ctrl[CTL_OVERFLOW] ? slack * 4u : slack,
+                                                    ch->h_ctrl[CTL_PATHOVF] ? maxpath * 8u : maxpath, side, s);
                 if (rst == BRX_OK) {
                     // the few long walks were redone by the sub chain with its own longer list; this chain keeps its
                     // list size (growing it x8 for every group of the grid is 8 GiB per chain after one event)
@@ -2245,6 +2275,7 @@ static int correct_batch_device_locked(brx_chain_t *ch, const uint8_t *d_bases, 
                     return rst;
             }
             if (!patched) {
+                side.clear();
                 if (ch->h_ctrl[CTL_OVERFLOW] != 0)
                     slack *= 4;
                 if (ch->h_ctrl[CTL_PATHOVF] != 0)
@@ -2278,6 +2309,12 @@ static int correct_batch_device_locked(brx_chain_t *ch, const uint8_t *d_bases, 
             compact_kernel<<<grid, 256, 0, s>>>(cur, cur_lens, d_offsets, n_reads, slack, cur_rev, d_out_offsets, d_out);
         }
         BRX_HIP(hipStreamSynchronize(s));
+        for (const SideRead &sr : side) { // the few reads that outgrew their slot: their bytes go straight to their place
+            uint64_t at = 0;
+            BRX_HIP(hipMemcpy(&at, d_out_offsets + sr.r, 8, hipMemcpyDeviceToHost));
+            if (!sr.bytes.empty())
+                BRX_HIP(hipMemcpy(d_out + at, sr.bytes.data(), sr.bytes.size(), hipMemcpyHostToDevice));
+        }
         return BRX_OK;
     }
 }

@@ -387,28 +387,40 @@ def test_greedy_parameters(raw_reads, solid_fixture_bytes):
             assert g == O.correct_record(om, r, False), (max_search, nbv)
 
 
-def test_output_slot_overflow_retry():
-    """a read whose correction grows it far beyond its staging slot (Graph re-inserting a 150-base
-    deletion): the batch is redone on the GPU with a larger slack, result identical to the oracle."""
+@pytest.mark.parametrize("redo_max", ["4096", "0"])
+def test_output_slot_overflow_retry(monkeypatch, redo_max):
+    """a read whose correction grows it far beyond its staging slot (Graph re-inserting a 150-base deletion).  Up to
+    4096 such reads are taken out and redone by a second chain with more slack; one that still does not fit its slot of
+    the batch is copied over its place in the compact output after the compaction (the rest of the batch is final).
+    More than that (BRX_REDO_MAX=0 forces it) and the whole batch is redone with 4x the slack, which the chain keeps.
+    Either way the oracle's bytes, in input order, with neighbours that must not be disturbed."""
+    monkeypatch.setenv("BRX_REDO_MAX", redo_max)
     rng = np.random.default_rng(7)
     k = 15   # large enough that the 3 kb random genome has no branching (k-1)-mers
     genome = bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=3000).tolist())
     ref = O.Solid(k)
     ref.set_seq(genome)
     gs = br_amd.Pcon.from_pcon_solid(ref.to_bytes())
-    reads = [genome[100:160] + genome[310:370], genome[500:560] + genome[900:960], genome[1000:1400]]
+    reads = [genome[2000:2300], genome[100:160] + genome[310:370], genome[1500:1530], genome[500:560] + genome[900:960],
+             genome[1000:1400], b"", genome[2500:2600]]
     for method in ("graph", "gap_size"):
-        om = O.build_methods(ref, [method], 5, 7)
-        chain = br_amd.Chain(gs, [(method, 5, 7)], two_side=True)
-        got = chain.correct_reads(reads)
-        exp = [O.correct_record(om, r, True) for r in reads]
-        assert got == exp
-        if method == "graph":
-            assert got[0] == genome[100:370] and got[1] == genome[500:960]
-            assert chain.last_stats()["overflow_retries"] >= 1
-            # the chain remembers the workspace it needed: the same batch again runs once
-            assert chain.correct_reads(reads) == exp
-            assert chain.last_stats()["overflow_retries"] == 0
+        for two_side in (True, False):
+            om = O.build_methods(ref, [method], 5, 7)
+            chain = br_amd.Chain(gs, [(method, 5, 7)], two_side=two_side)
+            got = chain.correct_reads(reads)
+            exp = [O.correct_record(om, r, two_side) for r in reads]
+            assert got == exp
+            if method == "graph":
+                st = chain.last_stats()
+                assert got[1] == genome[100:370] and got[3] == genome[500:960]
+                assert st["slot_overflow_reads"] >= 2
+                if redo_max == "0":
+                    assert st["overflow_retries"] >= 1
+                    # the chain remembers the workspace it needed: the same batch again runs once
+                    assert chain.correct_reads(reads) == exp and chain.last_stats()["overflow_retries"] == 0
+                else:
+                    assert st["overflow_retries"] == 0          # the two reads were redone on their own
+                    assert chain.correct_reads(reads) == exp
 
 
 @pytest.mark.parametrize("redo_max", ["4096", "0"])
