@@ -14,7 +14,7 @@ OUT=$PWD/gpurun_out/pmc_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/probe" -o p -- /root/repo/tools/probe_bench 16 64 > "$OUT/probe.log" 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -o f -- python3 /root/repo/bench.py --steps 1 --warmup 0 --no-cpu-baseline > "$OUT/fetch.log" 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -o w -- python3 /root/repo/bench.py --steps 1 --warmup 0 --no-cpu-baseline > "$OUT/write.log" 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -o f -- python3 /root/repo/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-e2e > "$OUT/fetch.log" 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -o w -- python3 /root/repo/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-e2e > "$OUT/write.log" 2>&1
 python3 /root/repo/profiles/pmc_summary.py "$OUT" "$TAG" || true
 # gpurun only merges gpurun_out/ back: re-run `python3 profiles/pmc_summary.py gpurun_out/pmc_$TAG $TAG` in the work tree

@@ -9,9 +9,9 @@ OUT=$PWD/gpurun_out/sq_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY \
-  --output-format csv -d "$OUT/a" -o a -- python3 /root/repo/bench.py --steps 1 --warmup 0 --no-cpu-baseline "$@" > "$OUT/a.log" 2>&1
+  --output-format csv -d "$OUT/a" -o a -- python3 /root/repo/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-e2e "$@" > "$OUT/a.log" 2>&1
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_THREAD_CYCLES_VALU SQ_WAVES \
-  --output-format csv -d "$OUT/b" -o b -- python3 /root/repo/bench.py --steps 1 --warmup 0 --no-cpu-baseline "$@" > "$OUT/b.log" 2>&1
+  --output-format csv -d "$OUT/b" -o b -- python3 /root/repo/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-e2e "$@" > "$OUT/b.log" 2>&1
 python3 - "$OUT" <<'PY'
 import csv, collections, glob, sys, json
 out = sys.argv[1]
@@ -27,7 +27,7 @@ for f in glob.glob(out + "/a/*kernel_trace.csv"):
         dur[name].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
 res = {}
 for name, c in agg.items():
-    if "correct_kernel" not in name and "final_count" not in name and "scatter" not in name:
+    if "correct_kernel" not in name and "one_kernel" not in name and "final_count" not in name and "scatter" not in name:
         continue
     d = {k: sum(v) / len(v) for k, v in c.items()}
     d["ms"] = sum(dur[name]) / max(len(dur[name]), 1)

@@ -61,8 +61,8 @@ res = {"tag": tag, "calibration": {"random_4B_load_bytes_as_counted": cal_rand,
                                    "stream_fraction_counted": cal_stream}, "bases_per_launch": bases, "kernels": summary}
 with open(os.path.join(here, f"{tag}_pmc_summary.json"), "w") as f:
     json.dump(res, f, indent=1)
-# correct_pass = every correct_kernel<G, M> instance (forward G=16 and reverse G=64 launches): launch-weighted mean
-ck = [v for k, v in summary.items() if k.startswith("correct_kernel<")]
+# correct_pass = every one_kernel<G, K> / correct_kernel<G, M> instance (forward G=8 and reverse G=64 launches): launch-weighted mean
+ck = [v for k, v in summary.items() if k.startswith("correct_kernel<") or k.startswith("one_kernel<")]
 if ck and bases:
     n_launch = sum(v["launches"] for v in ck)
     per_launch = sum(v["hbm_bytes_per_launch"] * v["launches"] for v in ck) / n_launch
