@@ -1397,6 +1397,40 @@ __global__ __launch_bounds__(256, 7) void one_kernel(PassParams p)
         gshift = lane & ~(G - 1);
         bcast_addr = (uint32_t)(lane | (G - 1)) * 4u;
         nb2 = 2u * ((uint32_t)gl + 1u);
+        if (G == 64) {
+            // One group per wave: everything below is wave-uniform.  The reverse pass of run_correction (src/lib.rs:48-55)
+            // reads the bases back to front WITHOUT complementing them, so hardly any of its k-mers is solid and nearly
+            // every round is "64 positions, no trigger": that round in a loop of its own, without the state dispatch,
+            // the trigger machinery and the register copies at their joins.  A round that does find a trigger (or an
+            // overflowed index line) is left to the general code below, which redoes its probes (they are pure).
+            while (have && st == ST_SCAN && !slow && n - i >= 65u && olen + 66u <= cap) {
+                const uint8_t c8 = ld(i + (uint32_t)lane);
+                uint32_t sc;
+                const uint64_t km = lane_kmer(kmer, (uint32_t)nuc2bit(c8), sc);
+                bool s1, u1 = false;
+                if (p.idx.lines) {
+                    const int pr = index_probe(p.idx, km, k);
+                    s1 = pr == 1;
+                    u1 = pr == 2;
+                } else {
+                    s1 = probe(p.bits, km, k);
+                }
+                const uint64_t bs = __ballot(s1);
+                const uint64_t trig = ~bs & ((bs << 1) | (prev ? 1ull : 0ull)); // mod.rs:73
+                if (__ballot(u1) | trig)
+                    break;
+                out[olen + (uint32_t)lane] = c8; // mod.rs:100
+                olen += 64u;
+                i += 64u;
+                kmer = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(km >> 32), 63) << 32) |
+                       (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)km, 63);
+                prev = (bs >> 63) & 1ull; // mod.rs:99
+                ev += ((lane == 0) ? 1u : 0u) + (1u << 8);
+                steps++;
+                if (++since_flush == 255u)
+                    flush();
+            }
+        }
         bool do_probe = false;
         uint64_t pk = 0;
         uint8_t ch = 0;
