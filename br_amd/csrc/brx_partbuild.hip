@@ -135,8 +135,8 @@ struct L1Args {
     uint64_t total;          // bases in the batch
     uint32_t n_items;
     int k, nbits, bits;      // digit = hash >> (nbits - bits)
-    uint32_t *matrix;        // [B][n_items] per-tile digit counts (hist) ...
-    const uint64_t *pos;     // ... and their exclusive scan (scatter)
+    uint32_t *matrix;        // [n_items][B] per-tile digit counts (hist): a tile's B counters are one coalesced row ...
+    const uint64_t *pos;     // ... and, same layout, where the tile's keys of each digit go (col_scan_* below)
     uint32_t *keys_out;      // hash with the digit stripped
 };
 
@@ -203,8 +203,105 @@ __global__ __launch_bounds__(256) void l1_hist_kernel(L1Args a)
                 atomicAdd(&lds[(uint32_t)(khash(kmer_at(pk, p, a.k), a.k) >> shift)], 1u);
         __syncthreads();
         for (uint32_t b = threadIdx.x; b < B; b += 256)
-            a.matrix[(uint64_t)b * a.n_items + item] = lds[b];
+            a.matrix[(uint64_t)item * B + b] = lds[b];
         __syncthreads();
+    }
+}
+
+// ---- positions from the [n_items][B] count matrix -------------------------------------------------------------------
+// pos[item][b] = (keys of all digits < b) + (keys of digit b in the tiles before `item`): a scan down the COLUMNS of a
+// tile-major matrix.  Tile-major because a tile then reads and writes its B counters as one coalesced row -- digit-major
+// ([B][n_items], one flat exclusive scan) made every tile touch B separate cache lines, twice in the histogram pass and
+// twice in the scatter: 0.25 random line accesses per key, which at the platform's ~55 G lines/s was most of level 1.
+// Three small passes over chunks of CH tiles: column sums per chunk, one block turning them into chunk bases (and the
+// digit offsets the next level needs), then the positions.
+__global__ __launch_bounds__(256) void col_scan_partial_kernel(const uint32_t *__restrict__ m, uint32_t n_items, uint32_t B, uint32_t CH,
+                                                               uint64_t *__restrict__ part)
+{
+    const uint32_t chunk = blockIdx.x;
+    const uint32_t lo = chunk * CH, hi = (lo + CH < n_items) ? lo + CH : n_items;
+    for (uint32_t b = threadIdx.x; b < B; b += 256) {
+        uint64_t sum = 0;
+        for (uint32_t it = lo; it < hi; it++)
+            sum += m[(uint64_t)it * B + b];
+        part[(uint64_t)chunk * B + b] = sum;
+    }
+}
+
+// block b: exclusive scan of column b of part[n_chunks][B] in place (n_chunks <= 2048: 8 per thread), its total -> coltot[b]
+__global__ __launch_bounds__(256) void col_scan_columns_kernel(uint64_t *__restrict__ part, uint32_t n_chunks, uint32_t B,
+                                                               uint64_t *__restrict__ coltot)
+{
+    __shared__ uint64_t wsum[4];
+    const uint32_t b = blockIdx.x;
+    const uint32_t per = (n_chunks + 255u) / 256u; // <= 8
+    const uint32_t c0 = threadIdx.x * per;
+    uint64_t v[8];
+    uint64_t mine = 0;
+    for (uint32_t q = 0; q < per && q < 8u; q++) {
+        const uint32_t c = c0 + q;
+        v[q] = c < n_chunks ? part[(uint64_t)c * B + b] : 0;
+        mine += v[q];
+    }
+    uint64_t incl = mine;
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint64_t t = __shfl_up(incl, d);
+        if ((threadIdx.x & 63) >= (unsigned)d)
+            incl += t;
+    }
+    if ((threadIdx.x & 63) == 63)
+        wsum[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    uint64_t base = 0;
+    for (uint32_t w = 0; w < (threadIdx.x >> 6); w++)
+        base += wsum[w];
+    uint64_t run = base + incl - mine;
+    for (uint32_t q = 0; q < per && q < 8u; q++) {
+        const uint32_t c = c0 + q;
+        if (c < n_chunks)
+            part[(uint64_t)c * B + b] = run;
+        run += v[q];
+    }
+    if (threadIdx.x == 255)
+        coltot[b] = base + incl;
+}
+
+// one wave: coff[b] = keys of all digits < b, coff[B] = *total = number of keys (B <= 1024)
+__global__ __launch_bounds__(64) void col_scan_digits_kernel(const uint64_t *__restrict__ coltot, uint32_t B, uint64_t *__restrict__ coff,
+                                                             unsigned long long *__restrict__ total)
+{
+    uint64_t carry = 0;
+    for (uint32_t b0 = 0; b0 < B; b0 += 64) {
+        const uint32_t b = b0 + threadIdx.x;
+        const uint64_t v = b < B ? coltot[b] : 0;
+        uint64_t incl = v;
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint64_t t = __shfl_up(incl, d);
+            if (threadIdx.x >= (unsigned)d)
+                incl += t;
+        }
+        if (b < B)
+            coff[b] = carry + incl - v;
+        carry += __shfl(incl, 63);
+    }
+    if (threadIdx.x == 0) {
+        coff[B] = carry;
+        *total = carry;
+    }
+}
+
+__global__ __launch_bounds__(256) void col_scan_positions_kernel(const uint32_t *__restrict__ m, uint32_t n_items, uint32_t B, uint32_t CH,
+                                                                 const uint64_t *__restrict__ part, const uint64_t *__restrict__ coff,
+                                                                 uint64_t *__restrict__ pos)
+{
+    const uint32_t chunk = blockIdx.x;
+    const uint32_t lo = chunk * CH, hi = (lo + CH < n_items) ? lo + CH : n_items;
+    for (uint32_t b = threadIdx.x; b < B; b += 256) {
+        uint64_t run = part[(uint64_t)chunk * B + b] + coff[b];
+        for (uint32_t it = lo; it < hi; it++) {
+            pos[(uint64_t)it * B + b] = run;
+            run += m[(uint64_t)it * B + b];
+        }
     }
 }
 
@@ -297,8 +394,8 @@ __global__ __launch_bounds__(256) void l1_scatter_kernel(L1Args a)
     const uint64_t child_mask = (1ull << shift) - 1ull;
     for (uint32_t item = blockIdx.x; item < a.n_items; item += gridDim.x) {
         for (uint32_t b = threadIdx.x; b < B; b += 256) {
-            cntv[b] = a.matrix[(uint64_t)b * a.n_items + item]; // the histogram pass already counted this tile
-            gbase[b] = a.pos[(uint64_t)b * a.n_items + item];
+            cntv[b] = a.matrix[(uint64_t)item * B + b]; // the histogram pass already counted this tile
+            gbase[b] = a.pos[(uint64_t)item * B + b];
         }
         uint32_t n_here;
         l1_prepare(a, item, pk, bnd, &sh_r0, n_here);
@@ -320,14 +417,6 @@ __global__ __launch_bounds__(256) void l1_scatter_kernel(L1Args a)
         }
         __syncthreads();
     }
-}
-
-// child offsets of level 1: coff[b] = pos[b * n_items], coff[B] = total
-__global__ void l1_coff_kernel(const uint64_t *__restrict__ pos, uint32_t B, uint32_t n_items, uint64_t *__restrict__ coff)
-{
-    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b <= B)
-        coff[b] = pos[(uint64_t)b * n_items];
 }
 
 // ---- levels >= 2: tiles inside parent buckets -----------------------------------------------------------------
@@ -918,6 +1007,8 @@ struct PartState {
     uint64_t matrix_cap = 0;
     uint64_t *d_pos = nullptr;         // exclusive scan of the matrix
     uint64_t pos_cap = 0;
+    uint64_t *d_colpart = nullptr;     // level 1: per-chunk column sums / bases of the tile-major matrix
+    uint64_t colpart_cap = 0;
     uint64_t *d_scan_tmp = nullptr;
     uint64_t scan_tmp_cap = 0;
     unsigned long long *d_scalars = nullptr; // [0] n_items, [1] total keys of the last scan
@@ -1024,7 +1115,7 @@ void part_free(brx_counter *c)
                 (void)hipFree(b.d_l1off);
         }
     for (void *p : {(void *)st->d_ntiles, (void *)st->d_item_off, (void *)st->d_item_parent, (void *)st->d_matrix,
-                    (void *)st->d_pos, (void *)st->d_scan_tmp, (void *)st->d_scalars, (void *)st->d_coff[0],
+                    (void *)st->d_pos, (void *)st->d_colpart, (void *)st->d_scan_tmp, (void *)st->d_scalars, (void *)st->d_coff[0],
                     (void *)st->d_coff[1], (void *)st->d_coff[2], (void *)st->d_coff[3], (void *)st->d_keys_mid,
                     (void *)st->d_keys_mid2, (void *)st->d_keys_fin,
                     (void *)st->d_merged, (void *)st->d_l1off_all, (void *)st->d_cnts, (void *)st->d_shift})
@@ -1146,8 +1237,22 @@ int part_add_batch(brx_counter *c, const uint8_t *d_bases, const uint64_t *d_off
         l1_hist_kernel<<<grid, 256, (size_t)B * 4, s>>>(a);
     }
     trace_stage(s, "partition level 1: histograms");
-    BRX_TRY(exclusive_scan_lens(st->d_matrix, (uint32_t)n_entries, st->d_scan_tmp, st->d_pos, st->d_scalars + 1, s));
-    l1_coff_kernel<<<(B + 1 + 255) / 256, 256, 0, s>>>(st->d_pos, B, n_items, b.d_l1off);
+    {
+        // positions of every (tile, digit) run and the digit offsets, from the tile-major counts (col_scan_* above)
+        KernelTimer t("offsets_scan", s);
+        uint32_t CH = 64;
+        while ((n_items + CH - 1) / CH > 2048u)
+            CH *= 2;
+        const uint32_t n_chunks = (n_items + CH - 1) / CH;
+        uint64_t capb = st->colpart_cap;
+        BRX_TRY(ensure_dev((void **)&st->d_colpart, &capb, ((uint64_t)n_chunks + 1) * B * 8));
+        st->colpart_cap = capb;
+        uint64_t *coltot = st->d_colpart + (uint64_t)n_chunks * B;
+        col_scan_partial_kernel<<<n_chunks, 256, 0, s>>>(st->d_matrix, n_items, B, CH, st->d_colpart);
+        col_scan_columns_kernel<<<B, 256, 0, s>>>(st->d_colpart, n_chunks, B, coltot);
+        col_scan_digits_kernel<<<1, 64, 0, s>>>(coltot, B, b.d_l1off, st->d_scalars + 1);
+        col_scan_positions_kernel<<<n_chunks, 256, 0, s>>>(st->d_matrix, n_items, B, CH, st->d_colpart, b.d_l1off, st->d_pos);
+    }
     {
         KernelTimer t("part_l1_scatter", s);
         const size_t lds1 = scatter_lds_bytes(L1_TILE, a.bits);
