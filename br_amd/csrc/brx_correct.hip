@@ -322,7 +322,7 @@ __device__ bool greedy_align(const GreedyLds &L, int gl, int m, int n, int nb, i
 __device__ __forceinline__ uint32_t walk_filter_index(uint64_t kmer, int G)
 {
     const uint32_t x = (uint32_t)(kmer ^ (kmer >> 23) ^ (kmer >> 41)) * 0x9E3779B1u;
-    return x >> (32 - 5 - (G == 8 ? 3 : G == 16 ? 4 : G == 32 ? 5 : 6));
+    return x >> (32 - 5 - (G == 4 ? 2 : G == 8 ? 3 : G == 16 ? 4 : G == 32 ? 5 : 6));
 }
 
 // index of the n-th (0-based) set bit of a small mask
@@ -1850,6 +1850,15 @@ int group_width(bool reverse_pass = false, bool indexed = false, uint32_t n_read
 
 constexpr uint32_t MAX_BLOCKS = 256u * 8u;
 
+// lanes per read of Graph's and GapSize's forward passes (BRX_GROUP_WALK = 4 / 8 / 16)
+int walk_group()
+{
+    // measured at 1 Gbp, k = 19 (fwd+rev ms, tools/method_bench.py): 16 lanes + bit vector 135 / 158 (graph / gap_size),
+    // 8 lanes + bit vector 140 / 145, 8 lanes + probe index 120 / 142, 4 lanes + probe index 123 / 151
+    static const int g = [] { const char *e = getenv("BRX_GROUP_WALK"); const int v = e ? atoi(e) : 8; return (v == 4 || v == 8 || v == 16) ? v : 8; }();
+    return g;
+}
+
 uint32_t pass_blocks(uint32_t n_reads, int G, bool balanced = false)
 {
     const uint32_t groups_per_block = 256u / (uint32_t)G;
@@ -1915,6 +1924,10 @@ int launch_method(const PassParams &p, int G, uint32_t blocks, size_t lds, hipSt
     }
     if (G <= 8 && M == BRX_ONE)
         correct_kernel<8, BRX_ONE><<<blocks, 256, lds, s>>>(p);
+    else if (G == 4 && (M == BRX_GRAPH || M == BRX_GAP_SIZE))
+        correct_kernel<4, (M == BRX_GRAPH || M == BRX_GAP_SIZE) ? M : BRX_GRAPH><<<blocks, 256, lds, s>>>(p);
+    else if (G == 8 && (M == BRX_GRAPH || M == BRX_GAP_SIZE))
+        correct_kernel<8, (M == BRX_GRAPH || M == BRX_GAP_SIZE) ? M : BRX_GRAPH><<<blocks, 256, lds, s>>>(p);
     else if (G <= 16)
         correct_kernel<16, M><<<blocks, 256, lds, s>>>(p);
     else if (G == 32)
@@ -2203,7 +2216,7 @@ static int correct_batch_device_locked(brx_chain_t *ch, const uint8_t *d_bases, 
             // one visited list per group that can be resident: walking methods run 16-lane groups or wider, so a grid of
             // pass_blocks(n_reads, 16) blocks of 16 groups bounds every width (a handful of redone reads needs a
             // handful of lists, not 32768 of them)
-            const uint64_t n_groups = (uint64_t)pass_blocks(n_reads, 16) * 16u;
+            const uint64_t n_groups = (uint64_t)pass_blocks(n_reads, walk_group()) * (256u / (uint32_t)walk_group());
             BRX_TRY(ensure((void **)&ch->d_path, &ch->path_bytes, n_groups * maxpath * 8ull));
         }
         const uint64_t stage_need = total_bases + (total_bases >> 2) * slack + 64ull * ((uint64_t)n_reads + 1) + 64;
@@ -2233,10 +2246,10 @@ static int correct_batch_device_locked(brx_chain_t *ch, const uint8_t *d_bases, 
                 // trigger-free) reverse scans of every method; walks probe 4 successors of one k-mer per round and
                 // gain nothing from shared lines.
                 const int mth = ch->methods[m].method;
-                // BRX_INDEX_FWD: bit mask of the methods whose FORWARD pass probes the index; measured per method
-                // (tools/method_bench.py, 1 Gbp): One 1.4x faster through it, Two/Graph/GapSize 2-6 % slower, Greedy
-                // 5 % faster at 1 Gbp but 8 % slower at 10 Gbp (200 M keys)
-                static const unsigned idx_fwd = [] { const char *e = getenv("BRX_INDEX_FWD"); return e ? (unsigned)atoi(e) : 1u; }();
+                // BRX_INDEX_FWD: bit mask (1 << method) of the methods whose FORWARD pass probes the index; measured per
+                // method (tools/method_bench.py, 1 Gbp): One 1.4x faster through it; Graph / GapSize 10-12 % faster with
+                // 8-lane groups (walk_group()); Two / Greedy (16-lane groups) see profiles/r2_one_kernel_ab.txt
+                static const unsigned idx_fwd = [] { const char *e = getenv("BRX_INDEX_FWD"); return e ? (unsigned)atoi(e) : 21u; }(); // One, Graph, GapSize
                 const bool use_idx = no_bits(ch->set) || ((idx_fwd >> mth) & 1u) || (dir == 1 && mth != BRX_GREEDY);
                 p.idx = use_idx ? idx : IdxView{nullptr, 0, 0, 0};
                 p.k = k;
@@ -2255,8 +2268,11 @@ static int correct_batch_device_locked(brx_chain_t *ch, const uint8_t *d_bases, 
                 p.maxpath = maxpath;
                 BRX_HIP(hipMemsetAsync(ch->d_ctrl + CTL_WORK, 0, 8, s));
                 int gw = dir ? group_width(true, false, n_reads) : G;
-                if (gw < 16 && mth != BRX_ONE)
-                    gw = 16; // only One has an 8-lane instance
+                if (gw < 16 && mth != BRX_ONE) {
+                    // the walking methods spend most of their rounds on one walk step = 4 probes: narrow groups keep the
+                    // lanes busy there (BRX_GROUP_WALK, default below); Two and Greedy need 16 lanes for their stage-1 probes
+                    gw = (mth == BRX_GRAPH || mth == BRX_GAP_SIZE) ? walk_group() : 16;
+                }
                 BRX_TRY(launch_pass(p, ch->methods[m], gw, s));
                 cur = ch->d_stage[pp];
                 cur_lens = ch->d_lens[pp];
