@@ -2249,7 +2249,7 @@ static int correct_batch_device_locked(brx_chain_t *ch, const uint8_t *d_bases, 
                 // BRX_INDEX_FWD: bit mask (1 << method) of the methods whose FORWARD pass probes the index; measured per
                 // method (tools/method_bench.py, 1 Gbp): One 1.4x faster through it; Graph / GapSize 10-12 % faster with
                 // 8-lane groups (walk_group()); Two / Greedy (16-lane groups) see profiles/r2_one_kernel_ab.txt
-                static const unsigned idx_fwd = [] { const char *e = getenv("BRX_INDEX_FWD"); return e ? (unsigned)atoi(e) : 21u; }(); // One, Graph, GapSize
+                static const unsigned idx_fwd = [] { const char *e = getenv("BRX_INDEX_FWD"); return e ? (unsigned)atoi(e) : 29u; }(); // One, Graph, Greedy, GapSize (Two: 69 ms through the bit vector, 72 through the index)
                 const bool use_idx = no_bits(ch->set) || ((idx_fwd >> mth) & 1u) || (dir == 1 && mth != BRX_GREEDY);
                 p.idx = use_idx ? idx : IdxView{nullptr, 0, 0, 0};
                 p.k = k;
