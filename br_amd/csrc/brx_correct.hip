@@ -1281,6 +1281,9 @@ __global__ __launch_bounds__(256, 7) void one_kernel(PassParams p)
     // events of this lane since the last flush: rounds | probes << 8 | triggers << 16 | fixes << 24 (flushed every
     // 255 rounds at most, so no field overflows)
     uint32_t ev = 0, since_flush = 0;
+    // the base this lane probes in the next SCAN round, loaded at the end of the round before (G < 64): a round is a
+    // dependent chain base load -> k-mer -> probe -> transition, and this takes the first link out of it
+    uint8_t pf_ch = 0;
 
     auto flush = [&]() {
         // per-field sums over the wave, then one atomic per counter: every 255 rounds, so it is noise (and keeps the
@@ -1443,7 +1446,10 @@ __global__ __launch_bounds__(256, 7) void one_kernel(PassParams p)
             if (st == ST_SCAN) {
                 const uint32_t pos = i + (uint32_t)gl;
                 const bool valid = pos < n;
-                ch = valid ? ld(pos) : (uint8_t)0;
+                if (G < 64)
+                    ch = pf_ch; // prefetched for exactly this i (every way into SCAN ends with the prefetch below)
+                else
+                    ch = valid ? ld(pos) : (uint8_t)0;
                 pk = lane_kmer(kmer, (uint32_t)nuc2bit(ch), scan);
                 do_probe = valid;
                 if (G <= 16) // all G codes of the group, for the k-mer the group leaves this round with
@@ -1504,6 +1510,32 @@ __global__ __launch_bounds__(256, 7) void one_kernel(PassParams p)
                     const uint32_t v = row_scan16(cd);
                     const uint32_t w0 = (uint32_t)__builtin_amdgcn_readlane((int)v, 15), w1 = (uint32_t)__builtin_amdgcn_readlane((int)v, 31);
                     win = ((uint64_t)w0 << 32) | w1;
+                }
+            } else if (st == ST_SCEN && (G == 8 || G == 16)) {
+                // get_score's look-aheads (exist/mod.rs:21-47) with a FIXED lane -> probe map (dealing the lanes to the
+                // surviving scenarios at run time cost more instructions than the rounds it saved):
+                //   stage A (sub == 0): lane 2s + j probes look-ahead j < 2 of scenario s -- a wrong scenario dies here;
+                //   stage B: the lowest scenario still in and not yet complete gets lanes 0.. for its look-aheads sub..c-1.
+                uint32_t off, j;
+                if (sub == 0u) {
+                    sc_s = (uint32_t)gl >> 1;
+                    j = (uint32_t)gl & 1u;
+                    sc_active = gl < 6 && !((failmask >> sc_s) & 1u) && j < c;
+                } else {
+                    sc_s = (uint32_t)__ffs(7u & ~failmask & ~passmask) - 1u;
+                    j = sub + (uint32_t)gl;
+                    sc_active = j < c;
+                }
+                off = 2u - sc_s; // I:2 S:1 D:0 (one.rs:57-63)
+                if (sc_active) {
+                    if (c + 3u <= (uint32_t)WB) {
+                        pk = ext(corr, off, j + 1u);
+                    } else {
+                        pk = corr;
+                        for (uint32_t q = 0; q <= j; q++)
+                            pk = add_nuc(pk, nuc2bit(ld(i + off + q)), mask);
+                    }
+                    do_probe = true;
                 }
             } else if (st == ST_SCEN) {
                 const uint32_t width = scen_width(sub, c, G, 0u, failmask);
@@ -1665,6 +1697,42 @@ __global__ __launch_bounds__(256, 7) void one_kernel(PassParams p)
                         st = ST_SCEN;
                     }
                 }
+            } else if (st == ST_SCEN && (G == 8 || G == 16)) {
+                const uint32_t badm = (uint32_t)(__ballot(sc_active && !sol) >> gshift) & GM32;
+                const uint32_t two = c < 2u ? c : 2u;
+                bool finished = false;
+                if (sub == 0u) {
+                    failmask |= ((badm & 3u) ? 1u : 0u) | ((badm & 12u) ? 2u : 0u) | ((badm & 48u) ? 4u : 0u);
+                    passmask = 0; // from here on: the scenarios whose c look-aheads all held
+                    sub = two;
+                    if (c <= 2u) {
+                        passmask = 7u & ~failmask;
+                        finished = true;
+                    }
+                } else {
+                    const uint32_t cur = (uint32_t)__ffs(7u & ~failmask & ~passmask) - 1u; // as in phase 1
+                    if (badm) {
+                        failmask |= 1u << cur;
+                        sub = two;
+                    } else {
+                        const uint32_t left = c - sub;
+                        sub += left < (uint32_t)G ? left : (uint32_t)G;
+                        if (sub >= c) {
+                            passmask |= 1u << cur;
+                            sub = two;
+                        }
+                    }
+                }
+                if (failmask == 7u) {
+                    fail = true; // exist/mod.rs:132-134
+                } else if (finished || (7u & ~failmask & ~passmask) == 0u) {
+                    if (passmask == 0u)
+                        fail = true;
+                    else if (__popc(passmask) == 1)
+                        apply_s = __ffs(passmask) - 1; // exist/mod.rs:135-137
+                    else
+                        st = ST_MORE;
+                }
             } else if (st == ST_SCEN) {
                 const bool bad = sc_active && !sol;
                 const uint32_t w_used = scen_width(sub, c, G, 0u, failmask);
@@ -1750,6 +1818,10 @@ __global__ __launch_bounds__(256, 7) void one_kernel(PassParams p)
                         st = ST_SCAN;
                 }
             }
+        }
+        if (G < 64 && have && !done && !retry && st == ST_SCAN) {
+            const uint32_t pos = i + (uint32_t)gl;
+            pf_ch = pos < n ? ld(pos) : (uint8_t)0;
         }
         if (done) {
             if (gl == 0) {
