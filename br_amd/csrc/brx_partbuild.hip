@@ -89,7 +89,7 @@ __device__ __forceinline__ uint32_t pack4(uint32_t w)
     return (x | (x >> 12)) & 0xffu;
 }
 
-constexpr uint32_t L1_TILE = 8192;                    // k-mer start positions per level-1 work item
+constexpr uint32_t L1_TILE = 4096;                    // k-mer start positions per level-1 work item (8192: scatter 5.4 ms, 4096: 4.3, 2048: 5.9 at 1 Gbp -- 35 KB of LDS = 4 blocks per CU)
 constexpr uint32_t PACK_WORDS = L1_TILE / 16 + 4;     // bases of the tile + k - 1 + slack, 16 per word
 constexpr uint32_t BND_WORDS = (L1_TILE + 64) / 32 + 2; // read-boundary bitmap of the same window
 

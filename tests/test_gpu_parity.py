@@ -804,3 +804,36 @@ def test_exchange_behind_the_abi_single_rank():
     finally:
         os.environ.pop("BRX_EXCHANGE_SELF_SEND", None)
         os.environ.pop("BRX_A2A_CHUNK", None)
+
+
+def test_comm_init_all_one_process():
+    """brx_comm_init_all: the one-process-many-GPUs form of the communicator (the reference's shape: one process,
+    threads).  One device here; the exchange through it equals the plain finish."""
+    import ctypes as C
+    L = _lib.lib()
+    devs = (C.c_int * 1)(0)
+    comms = (C.c_void_p * 1)()
+    _lib.check(L.brx_comm_init_all(1, devs, comms))
+    try:
+        w, r, d = C.c_int(-1), C.c_int(-1), C.c_int(-1)
+        _lib.check(L.brx_comm_info(comms[0], C.byref(w), C.byref(r), C.byref(d)))
+        assert (w.value, r.value, d.value) == (1, 0, 0)
+        k, a = 15, 1
+        cfg = synth.config(genome_len=30_000, read_len=2_000)
+        g = synth.genome_host(cfg)
+        bases, offs = synth.reads_host(cfg, g, 0, 150)
+        for strategy in (_lib.COUNT_SORTED, _lib.COUNT_DENSE):
+            plain = br_amd.Counter(k, 0, strategy)
+            plain.add_batch(bases, offs)
+            ref = plain.finish(a)
+            cnt = br_amd.Counter(k, 0, strategy)
+            cnt.add_batch(bases, offs)
+            if strategy == _lib.COUNT_SORTED:
+                gs = br_amd.Pcon.new(k, 0)
+                _lib.check(L.brx_exchange_build_partitioned(comms[0], cnt._h, a, gs._h, None))
+            else:
+                _lib.check(L.brx_exchange_reduce_counts(comms[0], cnt._h, a, None))   # world 1: nothing to add up
+                gs = cnt.finish(a)
+            assert gs.to_solid_bytes() == ref.to_solid_bytes()
+    finally:
+        L.brx_comm_free(comms[0])
