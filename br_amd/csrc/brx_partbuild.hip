@@ -484,7 +484,7 @@ __global__ __launch_bounds__(256) void ln_hist_kernel(LnArgs a)
     for (unsigned long long item = blockIdx.x; item < n_items; item += gridDim.x) {
         const uint64_t parent = a.item_parent[item];
         const uint64_t io = a.item_off[parent];
-        const uint64_t t = item - io, nt = a.item_off[parent + 1] - io;
+        const uint64_t t = item - io;
         for (uint32_t b = threadIdx.x; b < B; b += 256)
             lds[b] = 0;
         __syncthreads();
@@ -496,8 +496,61 @@ __global__ __launch_bounds__(256) void ln_hist_kernel(LnArgs a)
                 atomicAdd(&lds[(key[q] >> shift) & (B - 1u)], 1u);
         __syncthreads();
         for (uint32_t b = threadIdx.x; b < B; b += 256)
-            a.matrix[B * io + (uint64_t)b * nt + t] = lds[b];
+            a.matrix[B * (io + t) + b] = lds[b]; // tile-major inside the parent: one coalesced row per tile
         __syncthreads();
+    }
+}
+
+// positions of a level >= 2 from its tile-major counts: block p scans the columns of parent p's [ntiles][B] rows.
+// A parent's keys stay inside the parent's range, so pos = poff[p] + (keys of the parent's digits < b) + (keys of digit
+// b in the parent's tiles before t); coff[p*B + b] = where child (p, b) starts, coff[n_parents*B] = total.
+__global__ __launch_bounds__(256) void ln_colscan_kernel(const uint32_t *__restrict__ m, const uint64_t *__restrict__ poff,
+                                                         const uint64_t *__restrict__ item_off, uint64_t n_parents, uint32_t B,
+                                                         uint64_t *__restrict__ pos, uint64_t *__restrict__ coff)
+{
+    __shared__ uint64_t wsum[4];
+    for (uint64_t p = blockIdx.x; p < n_parents; p += gridDim.x) {
+        const uint64_t io = item_off[p], nt = item_off[p + 1] - io;
+        const uint32_t BPT = (B + 255u) / 256u; // digits per thread (1 or 2)
+        uint64_t tot[2] = {0, 0};
+        for (uint64_t t = 0; t < nt; t++)
+            for (uint32_t q = 0; q < BPT; q++) {
+                const uint32_t b = threadIdx.x * BPT + q;
+                if (b < B)
+                    tot[q] += m[B * (io + t) + b];
+            }
+        const uint64_t mine = tot[0] + tot[1];
+        uint64_t incl = mine;
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint64_t u = __shfl_up(incl, d);
+            if ((threadIdx.x & 63) >= (unsigned)d)
+                incl += u;
+        }
+        __syncthreads(); // (wsum of the previous parent has been read)
+        if ((threadIdx.x & 63) == 63)
+            wsum[threadIdx.x >> 6] = incl;
+        __syncthreads();
+        uint64_t base = poff[p];
+        for (uint32_t w = 0; w < (threadIdx.x >> 6); w++)
+            base += wsum[w];
+        uint64_t run[2];
+        run[0] = base + incl - mine;
+        run[1] = run[0] + tot[0];
+        for (uint32_t q = 0; q < BPT; q++) {
+            const uint32_t b = threadIdx.x * BPT + q;
+            if (b < B)
+                coff[p * B + b] = run[q];
+        }
+        for (uint64_t t = 0; t < nt; t++)
+            for (uint32_t q = 0; q < BPT; q++) {
+                const uint32_t b = threadIdx.x * BPT + q;
+                if (b < B) {
+                    pos[B * (io + t) + b] = run[q];
+                    run[q] += m[B * (io + t) + b];
+                }
+            }
+        if (p == n_parents - 1 && threadIdx.x == 0)
+            coff[n_parents * B] = poff[n_parents];
     }
 }
 
@@ -521,9 +574,9 @@ __global__ __launch_bounds__(256) void ln_scatter_kernel(LnArgs a)
     for (unsigned long long item = blockIdx.x; item < n_items; item += gridDim.x) {
         const uint64_t parent = a.item_parent[item];
         const uint64_t io = a.item_off[parent];
-        const uint64_t t = item - io, nt = a.item_off[parent + 1] - io;
+        const uint64_t t = item - io;
         for (uint32_t b = threadIdx.x; b < B; b += 256) {
-            const uint64_t mi = B * io + (uint64_t)b * nt + t;
+            const uint64_t mi = B * (io + t) + b;
             cntv[b] = a.matrix[mi];
             gbase[b] = a.pos[mi];
         }
@@ -548,23 +601,6 @@ __global__ __launch_bounds__(256) void ln_scatter_kernel(LnArgs a)
         }
         __syncthreads();
     }
-}
-
-// child offsets of a level >= 2: coff[p*B + b] = pos[B*item_off[p] + b*ntiles_p] (empty parents: the
-// position where the next non-empty parent starts), coff[n_parents*B] = total
-__global__ void ln_coff_kernel(const uint64_t *__restrict__ pos, const uint64_t *__restrict__ item_off, uint64_t n_parents,
-                               uint32_t B, uint64_t *__restrict__ coff)
-{
-    const uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (c > n_parents * B)
-        return;
-    if (c == n_parents * B) {
-        coff[c] = pos[(uint64_t)B * item_off[n_parents]];
-        return;
-    }
-    const uint64_t p = c / B, b = c % B;
-    const uint64_t io = item_off[p], nt = item_off[p + 1] - io;
-    coff[c] = pos[(uint64_t)B * io + b * nt];
 }
 
 // ---- final stage: one wavefront per fine bucket (4096 hashes) -----------------------------------------
@@ -1329,10 +1365,10 @@ static int run_level(PartState *st, int l, const uint32_t *keys_in, const uint64
             ln_hist_kernel<16><<<grid, 256, (size_t)B * 4, s>>>(a);
     }
     trace_stage(s, "  histograms done");
-    BRX_TRY(exclusive_scan_lens(st->d_matrix, (uint32_t)n_entries, st->d_scan_tmp, st->d_pos, st->d_scalars + 1, s));
     {
-        const uint64_t nc = n_parents * B + 1;
-        ln_coff_kernel<<<(unsigned)((nc + 255) / 256), 256, 0, s>>>(st->d_pos, st->d_item_off, n_parents, B, st->d_coff[l]);
+        KernelTimer t("offsets_scan", s);
+        const unsigned g = n_parents < 4096 ? (unsigned)n_parents : 4096u;
+        ln_colscan_kernel<<<g, 256, 0, s>>>(st->d_matrix, poff, st->d_item_off, n_parents, B, st->d_pos, st->d_coff[l]);
     }
     {
         KernelTimer t(tag_scatter, s);
