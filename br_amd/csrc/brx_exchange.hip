@@ -396,7 +396,6 @@ int brx_exchange_build_partitioned(brx_comm_t *cm, brx_counter_t *c, uint8_t abu
     void *d_list = nullptr;
     uint64_t n_mine = 0;
     BRX_TRY(brx_set_keylist_device(dst, &d_list, &n_mine, s));
-    std::vector<uint64_t> own_list_fallback;
     uint64_t *d_extracted = nullptr;
     if (!d_list) {
         // no list (it did not fit, or BRX_LAZY_BITS=0 builds that keep none): take it from the bit vector
@@ -417,7 +416,9 @@ int brx_exchange_build_partitioned(brx_comm_t *cm, brx_counter_t *c, uint8_t abu
     }
     int rc = BRX_OK;
     do {
-        hipError_t e = hipMemcpyAsync(cm->d_counts + me, &n_mine, 8, hipMemcpyHostToDevice, s);
+        hipError_t e = hipStreamSynchronize(s);
+        if (e == hipSuccess)
+            e = hipMemcpy(cm->d_counts + me, &n_mine, 8, hipMemcpyHostToDevice); // (a stack variable: not an async copy)
         if (e != hipSuccess) { rc = BRX_ERR_HIP; break; }
         // in-place all-gather: rank r's element sits at index r
         if (g_rccl.AllGather(cm->d_counts + me, cm->d_counts, 1, ncclUint64, cm->comm, s) != ncclSuccess) { rc = BRX_ERR_HIP; break; }
