@@ -1412,7 +1412,7 @@ __global__ __launch_bounds__(256, 7) void one_kernel(PassParams p)
                 const uint64_t km = lane_kmer(kmer, (uint32_t)nuc2bit(c8), sc);
                 bool s1, u1 = false;
                 if (p.idx.lines) {
-                    const int pr = index_probe(p.idx, km, k);
+                    const int pr = p.idx.line_bits ? index_probe_filtered(p.idx, km, k) : index_probe(p.idx, km, k);
                     s1 = pr == 1;
                     u1 = pr == 2;
                 } else {
@@ -1584,6 +1584,8 @@ __global__ __launch_bounds__(256, 7) void one_kernel(PassParams p)
             bool unres = false;
             if (do_probe) {
                 if (!slow) {
+                    // (through the occupancy bits this costs the forward pass 0.5 ms: its k-mers are mostly present, and
+                    // the extra dependent load only lengthens the round)
                     const int pr = index_probe(p.idx, pk, k);
                     sol = pr == 1;
                     unres = pr == 2;
@@ -2266,7 +2268,11 @@ static int correct_batch_device_locked(brx_chain_t *ch, const uint8_t *d_bases, 
     BRX_TRY(index_ensure(ch->set, s));
     IdxView idx{nullptr, 0, 0, 0};
     if (ch->set->idx_valid && (index_wanted(k) || no_bits(ch->set)))
-        idx = IdxView{ch->set->d_lines, 32u - ch->set->idx_log_lines, ch->set->idx_m, (uint32_t)k - ch->set->idx_m + 1u};
+        idx = IdxView{ch->set->d_lines, 32u - ch->set->idx_log_lines, ch->set->idx_m, (uint32_t)k - ch->set->idx_m + 1u,
+                      ch->set->idx_linebits ? (const uint32_t *)(ch->set->d_lines + (8ull << ch->set->idx_log_lines)) : nullptr};
+    static const bool use_linebits = [] { const char *e = getenv("BRX_LINE_BITS"); return !e || *e != '0'; }();
+    if (!use_linebits)
+        idx.line_bits = nullptr;
 
     const int n_dirs = ch->two_side ? 1 : 2;
     const int n_methods = (int)ch->methods.size();

@@ -13,7 +13,7 @@ namespace {
 template <bool CHAIN>
 __global__ __launch_bounds__(256) void index_insert_kernel(const uint64_t *__restrict__ keys, uint64_t n, uint64_t *__restrict__ lines,
                                                            uint32_t line_shift, uint32_t m, uint32_t w, int k,
-                                                           unsigned long long *__restrict__ n_overflow)
+                                                           unsigned long long *__restrict__ n_overflow, uint32_t *__restrict__ line_bits)
 {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     const uint32_t line_mask = 0xffffffffu >> line_shift;
@@ -34,6 +34,8 @@ __global__ __launch_bounds__(256) void index_insert_kernel(const uint64_t *__res
                 slot = (uint32_t)atomicAdd(L + 7, 1ull);
             if (slot < (uint32_t)IDX_SLOTS) {
                 L[slot] = h + 1ull;
+                if (slot == 0u) // the line's first key: mark the line as occupied (brx_index.hpp: line_bits)
+                    atomicOr(line_bits + (line >> 5), 1u << (line & 31u));
                 break;
             }
             {   // flag the line; at the key's home line also leave the key's signature bit
@@ -197,7 +199,7 @@ static int index_build_locked(brx_set *set, const uint64_t *d_keys, uint64_t n, 
             (void)hipFree(set->d_lines);
         set->d_lines = nullptr;
         set->lines_alloc = 0;
-        hipError_t e = hipMalloc((void **)&set->d_lines, n_lines * 64ull);
+        hipError_t e = hipMalloc((void **)&set->d_lines, n_lines * 64ull + n_lines / 8ull + 64ull); // lines + occupancy bits
         if (e != hipSuccess) {
             set_error("hipMalloc(%llu B probe index): %s", (unsigned long long)(n_lines * 64ull), hipGetErrorString(e));
             return BRX_ERR_NOMEM;
@@ -209,7 +211,7 @@ static int index_build_locked(brx_set *set, const uint64_t *d_keys, uint64_t n, 
     hipError_t e = hipMemsetAsync(d_ovf, 0, 8, s);
     if (e == hipSuccess) {
         KernelTimer t("index_zero", s);
-        e = hipMemsetAsync(set->d_lines, 0, n_lines * 64ull, s);
+        e = hipMemsetAsync(set->d_lines, 0, n_lines * 64ull + n_lines / 8ull + 64ull, s);
     }
     if (e == hipSuccess && n) {
         KernelTimer t("index_insert", s);
@@ -218,10 +220,10 @@ static int index_build_locked(brx_set *set, const uint64_t *d_keys, uint64_t n, 
             blocks = 256 * 16;
         if (no_bits(set))
             index_insert_kernel<true><<<(int)blocks, 256, 0, s>>>(d_keys, n, set->d_lines, 32u - (uint32_t)log_lines, (uint32_t)m,
-                                                                  (uint32_t)(k - m + 1), k, d_ovf);
+                                                                  (uint32_t)(k - m + 1), k, d_ovf, (uint32_t *)(set->d_lines + n_lines * 8ull));
         else
             index_insert_kernel<false><<<(int)blocks, 256, 0, s>>>(d_keys, n, set->d_lines, 32u - (uint32_t)log_lines, (uint32_t)m,
-                                                                   (uint32_t)(k - m + 1), k, d_ovf);
+                                                                   (uint32_t)(k - m + 1), k, d_ovf, (uint32_t *)(set->d_lines + n_lines * 8ull));
         e = hipGetLastError();
     }
     unsigned long long ovf = 0;
@@ -240,6 +242,7 @@ static int index_build_locked(brx_set *set, const uint64_t *d_keys, uint64_t n, 
     set->idx_overflow_keys = ovf;
     set->idx_exact = no_bits(set);
     set->idx_open = false;
+    set->idx_linebits = true; // this build filled the occupancy bits behind the lines
     set->idx_valid = true;
     return BRX_OK;
 }
@@ -287,7 +290,7 @@ int index_insert_reads(brx_set *set, const uint8_t *d_bases, const uint64_t *d_o
             return BRX_ERR_ARG;
         }
         uint64_t *nl = nullptr;
-        hipError_t e = hipMalloc((void **)&nl, (64ull << log_lines));
+        hipError_t e = hipMalloc((void **)&nl, (64ull << log_lines) + ((1ull << log_lines) >> 3) + 64ull); // (+ room for occupancy bits)
         if (e != hipSuccess) {
             set_error("hipMalloc(%llu B sparse set table): %s", (unsigned long long)(64ull << log_lines), hipGetErrorString(e));
             return BRX_ERR_NOMEM;
@@ -330,6 +333,7 @@ int index_insert_reads(brx_set *set, const uint8_t *d_bases, const uint64_t *d_o
     }
     set->idx_keys += added;
     set->idx_exact = true;
+    set->idx_linebits = false; // filled k-mer by k-mer: no occupancy bits
     set->idx_open = true;
     set->idx_valid = true;
     set->keylist_valid = false; // the table is the set now

@@ -39,6 +39,10 @@ struct IdxView {
     uint32_t line_shift;   // 32 - log2(number of lines)
     uint32_t m;            // minimizer length (odd, <= 15)
     uint32_t w;            // k - m + 1 windows
+    // one bit per line: set = the line holds at least one key.  4 MiB for 2^25 lines, i.e. L2-resident: a probe whose
+    // home line is empty is "absent" without fetching the line from HBM (79 % of the lines of the bench's set are empty,
+    // and the reverse pass of run_correction probes almost only absent k-mers).  nullptr: not kept for this index.
+    const uint32_t *line_bits = nullptr;
 };
 
 #if defined(__HIPCC__)
@@ -104,11 +108,17 @@ __device__ __forceinline__ uint32_t index_line_of(uint32_t mh, uint32_t line_shi
 
 // 1 = present, 0 = absent, 2 = the line overflowed and does not hold the key: ask the bit vector, or -- sparse sets,
 // whose keys chain into the following lines -- probe again with hop + 1
-__device__ __forceinline__ int index_probe(const IdxView &v, uint64_t fwd, int k, uint32_t hop = 0)
+// the key of a forward k-mer (canonical >> 1, + 1) and its home line
+__device__ __forceinline__ uint32_t index_locate(const IdxView &v, uint64_t fwd, int k, uint64_t &key)
 {
     const uint64_t rc = revcomp(fwd, k);
-    const uint64_t key = (((popc64(fwd) & 1) ? rc : fwd) >> 1) + 1ull;
-    const uint32_t line = (index_line_of(minimizer_of(fwd, rc, v.m, v.w), v.line_shift) + hop) & (0xffffffffu >> v.line_shift);
+    key = (((popc64(fwd) & 1) ? rc : fwd) >> 1) + 1ull;
+    return index_line_of(minimizer_of(fwd, rc, v.m, v.w), v.line_shift);
+}
+
+__device__ __forceinline__ int index_probe_at(const IdxView &v, uint64_t key, uint32_t home, uint32_t hop)
+{
+    const uint32_t line = (home + hop) & (0xffffffffu >> v.line_shift);
     const ulonglong2 *L = reinterpret_cast<const ulonglong2 *>(v.lines + (uint64_t)line * 8ull);
     const ulonglong2 q0 = L[0], q1 = L[1], q2 = L[2], q3 = L[3];
     // `|`, not `||`: with short-circuit evaluation the compiler loads slot 0 first and fetches the rest of
@@ -119,6 +129,23 @@ __device__ __forceinline__ int index_probe(const IdxView &v, uint64_t fwd, int k
     const uint32_t hdr_hi = (uint32_t)(q3.y >> 32); // bit 31 = overflowed, bits 0..30 = signature of the keys turned away
     const bool more = (hdr_hi >> 31) && (hop != 0u || ((hdr_hi >> idx_sig_index(key)) & 1u));
     return found ? 1 : (more ? 2 : 0);
+}
+
+__device__ __forceinline__ int index_probe(const IdxView &v, uint64_t fwd, int k, uint32_t hop = 0)
+{
+    uint64_t key;
+    const uint32_t home = index_locate(v, fwd, k, key);
+    return index_probe_at(v, key, home, hop);
+}
+
+// index_probe through the line-occupancy bits: an empty home line answers "absent" from a 4-byte load that hits L2
+__device__ __forceinline__ int index_probe_filtered(const IdxView &v, uint64_t fwd, int k)
+{
+    uint64_t key;
+    const uint32_t home = index_locate(v, fwd, k, key);
+    if (!((v.line_bits[home >> 5] >> (home & 31u)) & 1u))
+        return 0;
+    return index_probe_at(v, key, home, 0u);
 }
 // find-or-insert of one k-mer into a chained table (sparse sets filled k-mer by k-mer, `br large-kmer`): true if the
 // key was not there.  Threads race for the first empty slot of a line with a CAS; slots never empty again, so

@@ -74,7 +74,8 @@ struct brx_set {
     // probe index over the same set (brx_index.hpp): built on demand, invalidated by every mutation
     // of the bits that goes through the ABI
     uint64_t *d_lines;       // 8 u64 per line
-    uint64_t lines_alloc;    // lines allocated
+    uint64_t lines_alloc;    // lines allocated (the allocation also holds lines_alloc / 8 bytes of occupancy bits behind the lines)
+    bool idx_linebits = false; // the occupancy bits are current (indexes built from a key list)
     uint32_t idx_log_lines;
     uint32_t idx_m;
     bool idx_valid;
