@@ -357,6 +357,36 @@ __device__ __forceinline__ uint32_t scen_width(uint32_t sub, uint32_t c, int G, 
     return left < cap ? left : cap;
 }
 
+template <int D>
+__device__ __forceinline__ uint32_t dpp_row_shr(uint32_t v)
+{
+    // lane l of a 16-lane row reads lane l - D of the same row; lanes without such a source read 0
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x110 + D, 0xf, 0xf, true);
+}
+
+// codes of the row's lanes first..this one, this lane's code in bits 0-1, the lane before in bits 2-3, ...
+__device__ __forceinline__ uint32_t row_scan16(uint32_t code)
+{
+    uint32_t v = code;
+    v |= dpp_row_shr<1>(v) << 2;
+    v |= dpp_row_shr<2>(v) << 4;
+    v |= dpp_row_shr<4>(v) << 8;
+    v |= dpp_row_shr<8>(v) << 16;
+    return v;
+}
+// this lane's k-mer in a 64-lane group: `carry` extended by the codes of lanes 0..lane (own row by the DPP scan, the two
+// rows before by row_bcast:15; rows 0 / 1 take those words from `carry`)
+__device__ __forceinline__ uint64_t lane_kmer64_dpp(uint64_t carry, uint32_t code, int lane, uint64_t mask)
+{
+    const uint32_t v = row_scan16(code);
+    const uint32_t clo = (uint32_t)carry, chi = (uint32_t)(carry >> 32);
+    const uint32_t b1 = (uint32_t)__builtin_amdgcn_update_dpp((int)clo, (int)v, 0x142 /* row_bcast:15 */, 0xe, 0xf, false);
+    const uint32_t old2 = (lane < 16) ? chi : clo;
+    const uint32_t b2 = (uint32_t)__builtin_amdgcn_update_dpp((int)old2, (int)b1, 0x142, 0xc, 0xf, false);
+    const uint32_t jb = 2u * ((uint32_t)(lane & 15) + 1u);
+    return (((((uint64_t)b2 << 32) | b1) << jb) | v) & mask; // jb <= 32
+}
+
 template <int G, int M>
 // One fits 80 VGPRs without spilling: 6 waves per SIMD instead of 5 (the kernel waits on memory 60 % of the
 // time, measured 8 % faster), and its 64-lane form (no group shuffles to keep) fits 72: 7 waves; the other methods
@@ -499,6 +529,36 @@ __global__ __launch_bounds__(256, (M == BRX_ONE ? (G == 64 ? 7 : 6) : (M == BRX_
     fetch();
 
     while (__any(have)) {
+        if (G == 64) {
+            // trigger-free rounds of the 64-lane form (every method's reverse pass is almost only these) in a loop of
+            // their own, as in one_kernel: 64 positions, one probe each, ballot, accept; a round with a trigger or an
+            // overflowed index line is left to the general code below, which redoes its (pure) probes
+            while (have && st == ST_SCAN && !slow && n - i >= 65u && olen + 66u <= cap) {
+                const uint8_t c8 = ld(i + (uint32_t)lane);
+                const uint64_t km = lane_kmer64_dpp(kmer, (uint32_t)nuc2bit(c8), lane, mask);
+                bool s1, u1 = false;
+                if (p.idx.lines) {
+                    const int pr = p.idx.line_bits ? index_probe_filtered(p.idx, km, k) : index_probe(p.idx, km, k);
+                    s1 = pr == 1;
+                    u1 = pr == 2;
+                } else {
+                    s1 = probe(p.bits, km, k);
+                }
+                const uint64_t bs = __ballot(s1);
+                const uint64_t trig = ~bs & ((bs << 1) | (prev ? 1ull : 0ull)); // mod.rs:73
+                if (__ballot(u1) | trig)
+                    break;
+                out[olen + (uint32_t)lane] = c8; // mod.rs:100
+                olen += 64u;
+                i += 64u;
+                kmer = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(km >> 32), 63) << 32) |
+                       (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)km, 63);
+                prev = (bs >> 63) & 1ull; // mod.rs:99
+                n_rounds += 1u;
+                n_probes += 64u;
+                steps++;
+            }
+        }
         uint32_t ev = 0;
         bool do_probe = false;
         uint64_t pk = 0;
@@ -1219,23 +1279,6 @@ __global__ __launch_bounds__(256, (M == BRX_ONE ? (G == 64 ? 7 : 6) : (M == BRX_
 //   - event counters are one packed register, flushed per wave every 256 rounds.
 // G = 8 / 16: groups inside one DPP row.  G = 64: one group per wave, group state in scalar registers.
 // ======================================================================================================================
-template <int D>
-__device__ __forceinline__ uint32_t dpp_row_shr(uint32_t v)
-{
-    // lane l of a 16-lane row reads lane l - D of the same row; lanes without such a source read 0
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x110 + D, 0xf, 0xf, true);
-}
-
-// codes of the row's lanes first..this one, this lane's code in bits 0-1, the lane before in bits 2-3, ...
-__device__ __forceinline__ uint32_t row_scan16(uint32_t code)
-{
-    uint32_t v = code;
-    v |= dpp_row_shr<1>(v) << 2;
-    v |= dpp_row_shr<2>(v) << 4;
-    v |= dpp_row_shr<4>(v) << 8;
-    v |= dpp_row_shr<8>(v) << 16;
-    return v;
-}
 __device__ __forceinline__ uint32_t row_scan4(uint32_t code)
 {
     uint32_t v = code;
@@ -1369,17 +1412,8 @@ __global__ __launch_bounds__(256, 7) void one_kernel(PassParams p)
             return ((carry << nb2) | v) & mask; // nb2 <= 32
         } else {
             // 64 lanes = 4 rows: own row's codes + the 16-base words of the two rows before (row 0 / 1: of `carry`)
-            const uint32_t v = row_scan16(code);
-            scan_out = v;
-            const uint32_t clo = (uint32_t)carry, chi = (uint32_t)(carry >> 32);
-            // b1 = full word of the previous row (lane 15 of it); row 0 keeps carry's low word
-            const uint32_t b1 = (uint32_t)__builtin_amdgcn_update_dpp((int)clo, (int)v, 0x142 /* row_bcast:15 */, 0xe, 0xf, false);
-            // b2 = word of the row before that: rows 2, 3 from b1's row_bcast; row 1 = carry low, row 0 = carry high
-            const uint32_t old2 = (lane < 16) ? chi : clo;
-            const uint32_t b2 = (uint32_t)__builtin_amdgcn_update_dpp((int)old2, (int)b1, 0x142, 0xc, 0xf, false);
-            const uint32_t jb = 2u * ((uint32_t)(lane & 15) + 1u);
-            const uint64_t hi = ((uint64_t)b2 << 32) | b1;
-            return ((hi << jb) | v) & mask; // jb <= 32
+            scan_out = 0;
+            return lane_kmer64_dpp(carry, code, lane, mask);
         }
     };
     // km extended by window bases b0 .. b0+nb-1 (b0 + nb <= WB; the window holds seq[i .. i+WB) at the trigger)
