@@ -1963,8 +1963,9 @@ int walk_group()
 {
     // measured at 1 Gbp, k = 19 (fwd+rev ms, tools/method_bench.py): 16 lanes + bit vector 135 / 158 (graph / gap_size),
     // 8 lanes + bit vector 140 / 145, 8 lanes + probe index 120 / 142, 4 lanes + probe index 123 / 151
-    static const int g = [] { const char *e = getenv("BRX_GROUP_WALK"); const int v = e ? atoi(e) : 8; return (v == 4 || v == 8 || v == 16) ? v : 8; }();
-    return g;
+    const char *e = getenv("BRX_GROUP_WALK"); // (read on every use: the fuzzers sweep it)
+    const int v = e ? atoi(e) : 8;
+    return (v == 4 || v == 8 || v == 16) ? v : 8;
 }
 
 uint32_t pass_blocks(uint32_t n_reads, int G, bool balanced = false)
@@ -2304,9 +2305,9 @@ static int correct_batch_device_locked(brx_chain_t *ch, const uint8_t *d_bases, 
     if (ch->set->idx_valid && (index_wanted(k) || no_bits(ch->set)))
         idx = IdxView{ch->set->d_lines, 32u - ch->set->idx_log_lines, ch->set->idx_m, (uint32_t)k - ch->set->idx_m + 1u,
                       ch->set->idx_linebits ? (const uint32_t *)(ch->set->d_lines + (8ull << ch->set->idx_log_lines)) : nullptr};
-    static const bool use_linebits = [] { const char *e = getenv("BRX_LINE_BITS"); return !e || *e != '0'; }();
-    if (!use_linebits)
-        idx.line_bits = nullptr;
+    if (const char *e = getenv("BRX_LINE_BITS")) // (A/B and fuzzers: 0 = do not consult the occupancy bits)
+        if (*e == '0')
+            idx.line_bits = nullptr;
 
     const int n_dirs = ch->two_side ? 1 : 2;
     const int n_methods = (int)ch->methods.size();
@@ -2361,7 +2362,8 @@ static int correct_batch_device_locked(brx_chain_t *ch, const uint8_t *d_bases, 
                 // BRX_INDEX_FWD: bit mask (1 << method) of the methods whose FORWARD pass probes the index; measured per
                 // method (tools/method_bench.py, 1 Gbp): One 1.4x faster through it; Graph / GapSize 10-12 % faster with
                 // 8-lane groups (walk_group()); Two / Greedy (16-lane groups) see profiles/r2_one_kernel_ab.txt
-                static const unsigned idx_fwd = [] { const char *e = getenv("BRX_INDEX_FWD"); return e ? (unsigned)atoi(e) : 29u; }(); // One, Graph, Greedy, GapSize (Two: 69 ms through the bit vector, 72 through the index)
+                const char *e_fwd = getenv("BRX_INDEX_FWD");
+                const unsigned idx_fwd = e_fwd ? (unsigned)atoi(e_fwd) : 29u; // One, Graph, Greedy, GapSize (Two: 69 ms through the bit vector, 72 through the index)
                 const bool use_idx = no_bits(ch->set) || ((idx_fwd >> mth) & 1u) || (dir == 1 && mth != BRX_GREEDY);
                 p.idx = use_idx ? idx : IdxView{nullptr, 0, 0, 0};
                 p.k = k;

@@ -63,7 +63,10 @@ while time.time() < t_end:
     if "two" in names and c == 0:
         c = 1  # Two with -C 0 makes the reference panic (two.rs:265: a scenario whose apply() is None scores 0 == c)
     two_side = bool(rng.random() < 0.3)
-    env = {"BRX_GROUP": str(rng.choice(["", "8", "16", "32", "64"])), "BRX_INDEX": str(rng.choice(["1", "1", "0"])),
+    env = {"BRX_GROUP": str(rng.choice(["", "4", "8", "16", "32", "64"])), "BRX_INDEX": str(rng.choice(["1", "1", "0"])),
+           "BRX_GROUP_WALK": str(rng.choice(["", "4", "8", "16"])), "BRX_LINE_BITS": str(rng.choice(["", "0"])),
+           "BRX_INDEX_FWD": str(rng.choice(["", "1", "31"])), "BRX_REDO_MAX": str(rng.choice(["", "", "0"])),
+           "BRX_MAXPATH": str(rng.choice(["", "", "3"])),
            "BRX_INDEX_MIN_K": "5", "BRX_FORCE_SPARSE": str(rng.choice(["0", "0", "1"])),
            "BRX_LAZY_BITS": str(rng.choice(["1", "0"])), "BRX_INDEX_LOG_LINES": str(rng.choice(["0", "0", "5"]))}
     for key, v in env.items():
