@@ -89,6 +89,10 @@ __device__ __forceinline__ uint32_t pack4(uint32_t w)
     return (x | (x >> 12)) & 0xffu;
 }
 
+#ifndef BRX_XCD_ITEMS
+#define BRX_XCD_ITEMS 1
+#endif
+constexpr bool XCD_ITEMS = BRX_XCD_ITEMS != 0;
 constexpr uint32_t L1_TILE = 4096;                    // k-mer start positions per level-1 work item (8192: scatter 5.4 ms, 4096: 4.3, 2048: 5.9 at 1 Gbp -- 35 KB of LDS = 4 blocks per CU)
 constexpr uint32_t PACK_WORDS = L1_TILE / 16 + 4;     // bases of the tile + k - 1 + slack, 16 per word
 constexpr uint32_t BND_WORDS = (L1_TILE + 64) / 32 + 2; // read-boundary bitmap of the same window
@@ -122,6 +126,30 @@ __device__ __forceinline__ uint64_t kmer_at(const uint32_t *__restrict__ pk, uin
     const uint64_t lo = pk[w + 2];
     const uint64_t val = sh ? ((hi << sh) | (lo >> (32u - sh))) : hi;
     return val >> (64 - 2 * k);
+}
+
+// ---- which work items a workgroup takes -------------------------------------------------------------------------------------
+// Workgroups are dealt round-robin over the 8 XCDs (blocks b and b + 8 share one: MI355X_MICROARCH.md, Workgroup
+// dispatch), and tile t + 1 of a scatter appends each digit's keys right behind tile t's -- 32-byte runs at 8 keys per
+// digit.  With the plain grid-stride loop neighbouring tiles sit on different XCDs, so every 128-byte line of the output
+// is written in pieces from four L2s that cannot merge them.  Here the blocks that share an XCD take one contiguous
+// eighth of the items and walk it side by side, so the pieces of a line meet in one L2 and leave as whole lines.
+// Speed only: every item is taken exactly once whatever the placement really is.
+struct ItemRange {
+    unsigned long long first, end, step;
+};
+__device__ __forceinline__ ItemRange xcd_items(unsigned long long n_items)
+{
+    const unsigned long long G = gridDim.x, b = blockIdx.x;
+    if (G < 8ull || !XCD_ITEMS)
+        return {b, n_items, G};
+    const unsigned long long x = b & 7ull, j = b >> 3;
+    const unsigned long long R = (n_items + 7ull) >> 3;
+    const unsigned long long lo = x * R;
+    unsigned long long hi = lo + R;
+    if (hi > n_items)
+        hi = n_items;
+    return {lo + j, hi, (G - x + 7ull) >> 3}; // blocks with label x: x, x + 8, ... < G
 }
 
 // ---- level 1: tiles of the flat base stream ---------------------------------------------------------------
@@ -193,7 +221,8 @@ __global__ __launch_bounds__(256) void l1_hist_kernel(L1Args a)
     __shared__ uint32_t sh_r0;
     const uint32_t B = 1u << a.bits;
     const int shift = a.nbits - a.bits;
-    for (uint32_t item = blockIdx.x; item < a.n_items; item += gridDim.x) {
+    const ItemRange ir = xcd_items(a.n_items);
+    for (uint32_t item = (uint32_t)ir.first; item < (uint32_t)ir.end; item += (uint32_t)ir.step) {
         for (uint32_t b = threadIdx.x; b < B; b += 256)
             lds[b] = 0;
         uint32_t n_here;
@@ -392,7 +421,8 @@ __global__ __launch_bounds__(256) void l1_scatter_kernel(L1Args a)
     uint32_t *lcur = lofs + B;
     const int shift = a.nbits - a.bits;
     const uint64_t child_mask = (1ull << shift) - 1ull;
-    for (uint32_t item = blockIdx.x; item < a.n_items; item += gridDim.x) {
+    const ItemRange ir = xcd_items(a.n_items);
+    for (uint32_t item = (uint32_t)ir.first; item < (uint32_t)ir.end; item += (uint32_t)ir.step) {
         for (uint32_t b = threadIdx.x; b < B; b += 256) {
             cntv[b] = a.matrix[(uint64_t)item * B + b]; // the histogram pass already counted this tile
             gbase[b] = a.pos[(uint64_t)item * B + b];
@@ -481,7 +511,8 @@ __global__ __launch_bounds__(256) void ln_hist_kernel(LnArgs a)
     const uint32_t B = 1u << a.bits;
     const int shift = a.rem_in - a.bits;
     const unsigned long long n_items = *a.n_items;
-    for (unsigned long long item = blockIdx.x; item < n_items; item += gridDim.x) {
+    const ItemRange ir = xcd_items(n_items);
+    for (unsigned long long item = ir.first; item < ir.end; item += ir.step) {
         const uint64_t parent = a.item_parent[item];
         const uint64_t io = a.item_off[parent];
         const uint64_t t = item - io;
@@ -571,7 +602,8 @@ __global__ __launch_bounds__(256) void ln_scatter_kernel(LnArgs a)
     const uint32_t child_mask = (1u << shift) - 1u;
     OUT *out = (OUT *)a.keys_out;
     const unsigned long long n_items = *a.n_items;
-    for (unsigned long long item = blockIdx.x; item < n_items; item += gridDim.x) {
+    const ItemRange ir = xcd_items(n_items);
+    for (unsigned long long item = ir.first; item < ir.end; item += ir.step) {
         const uint64_t parent = a.item_parent[item];
         const uint64_t io = a.item_off[parent];
         const uint64_t t = item - io;
