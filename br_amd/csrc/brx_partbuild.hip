@@ -852,16 +852,20 @@ __global__ __launch_bounds__(64 * P3_WAVES) void final_count_kernel(const uint16
 // (open addressing, entry = valid | key << 11 | count), and the entries with count > abundance are listed.  That
 // replaces the last level's histogram + scatter and the per-4096-hash counting pass.  A TEAM of 256 (one
 // workgroup) or 64 lanes (one wave) takes a bucket; a bucket with more keys than the table can take is done in
-// 2^p passes over disjoint key ranges, and a pass whose distinct keys still do not fit is repeated finer.
+// 2^lp passes over disjoint key ranges.  lp is chosen for the DISTINCT keys expected -- n x the ratio hf_sample_kernel
+// measured on a few buckets: at 20x coverage a bucket of 48 000 keys has ~10 000 different ones -- and a pass whose
+// keys still do not fit is repeated 4x finer.
 constexpr uint32_t HF_VALID = 0x80000000u;
 constexpr int HF_CHUNK = 8;
+constexpr uint32_t HF_MAX_TRIES = 192; // probes before a key calls the table full (a cluster that long means it nearly is)
 __host__ __device__ constexpr uint32_t hf_ebuf(int team) { return team > 64 ? 1024u : 512u; }
 
 template <int TEAM, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void hash_final_kernel(const uint32_t *__restrict__ keys, const uint64_t *__restrict__ off,
                                                          uint64_t n_buckets, int R, uint32_t abundance, uint32_t log_t,
                                                          uint64_t *__restrict__ emit_keys, uint64_t emit_cap,
-                                                         unsigned long long *__restrict__ emit_n)
+                                                         unsigned long long *__restrict__ emit_n,
+                                                         const unsigned long long *__restrict__ dup)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t hf_lds[];
     constexpr int TEAMS = BLOCK / TEAM;
@@ -898,18 +902,26 @@ __global__ __launch_bounds__(BLOCK) void hash_final_kernel(const uint32_t *__res
         ctl[1] = 0;
     }
     team_sync();
+    // distinct keys expected per key of a bucket (1 when nothing was sampled), with a quarter of room on top
+    float ratio = 1.0f;
+    if (dup) {
+        const float d = (float)dup[0], t = (float)dup[1];
+        if (t > 0.0f)
+            ratio = fminf(1.0f, 1.25f * d / t + 0.01f);
+    }
     const uint64_t n_teams = (uint64_t)gridDim.x * TEAMS;
     for (uint64_t b = (uint64_t)blockIdx.x * TEAMS + team; b < n_buckets; b += n_teams) { // (team-uniform trip count)
         const uint64_t s0 = off[b], n = off[b + 1] - s0;
         if (n == 0)
             continue;
-        // passes: 2^lp disjoint ranges of the R-bit key, each expected to hold <= 5/8 T keys
+        // passes: 2^lp disjoint ranges of the R-bit key, each expected to bring <= 5/8 T DISTINCT keys
+        const uint64_t n_eff = (uint64_t)((float)n * ratio) + 1ull;
         uint32_t lp = 0;
-        while (lp < (uint32_t)R && (n >> lp) > (uint64_t)(T / 8u * 5u))
+        while (lp < (uint32_t)R && (n_eff >> lp) > (uint64_t)(T / 8u * 5u))
             lp++;
         for (uint32_t pass = 0; pass < (1u << lp);) {
-            for (uint32_t q = tl; q < T; q += TEAM)
-                tab[q] = 0;
+            for (uint32_t q = tl * 4u; q < T; q += TEAM * 4u) // 16 bytes per lane and store (T >= 4 * TEAM)
+                *(uint4 *)(tab + q) = make_uint4(0u, 0u, 0u, 0u);
             team_sync();
             for (uint64_t i0 = 0; i0 < n; i0 += (uint64_t)TEAM * HF_CHUNK) {
               // HF_CHUNK independent loads in flight per thread, then the (LDS-latency-bound) inserts
@@ -938,7 +950,7 @@ __global__ __launch_bounds__(BLOCK) void hash_final_kernel(const uint32_t *__res
                             atomicAdd(&tab[h], 1u);
                         break;
                     }
-                    if (tries >= T) { // table full of other keys: this pass needs a finer split
+                    if (tries >= HF_MAX_TRIES) { // the table is (as good as) full of other keys: this pass needs a finer split
                         ctl[1] = 1;
                         break;
                     }
@@ -962,18 +974,23 @@ __global__ __launch_bounds__(BLOCK) void hash_final_kernel(const uint32_t *__res
             }
             // list the solid entries: into the team's buffer (a pass holds at most 5/8 T / (abundance + 1) of them; what
             // does not fit goes straight to the global list), one flush per pass
-            for (uint32_t q0 = 0; q0 < T; q0 += TEAM) {
-                const uint32_t e = tab[q0 + tl];
-                const uint32_t cnt = e & 0x7ffu;
-                if ((e & HF_VALID) && (cnt > 255u ? 255u : cnt) > abundance) {
-                    const unsigned long long hk = (b << R) | (uint64_t)((e >> 11) & 0xfffffu);
-                    const uint32_t pos = atomicAdd(&ctl[0], 1u);
-                    if (pos < EB) {
-                        ebuf[pos] = hk;
-                    } else {
-                        const unsigned long long gp = atomicAdd(emit_n, 1ull);
-                        if (gp < emit_cap)
-                            emit_keys[gp] = hk;
+            for (uint32_t q0 = tl * 4u; q0 < T; q0 += TEAM * 4u) { // four entries per lane and LDS read
+                const uint4 e4 = *(const uint4 *)(tab + q0);
+                const uint32_t ev[4] = {e4.x, e4.y, e4.z, e4.w};
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const uint32_t e = ev[j];
+                    const uint32_t cnt = e & 0x7ffu;
+                    if ((e & HF_VALID) && (cnt > 255u ? 255u : cnt) > abundance) {
+                        const unsigned long long hk = (b << R) | (uint64_t)((e >> 11) & 0xfffffu);
+                        const uint32_t pos = atomicAdd(&ctl[0], 1u);
+                        if (pos < EB) {
+                            ebuf[pos] = hk;
+                        } else {
+                            const unsigned long long gp = atomicAdd(emit_n, 1ull);
+                            if (gp < emit_cap)
+                                emit_keys[gp] = hk;
+                        }
                     }
                 }
             }
@@ -986,6 +1003,57 @@ __global__ __launch_bounds__(BLOCK) void hash_final_kernel(const uint32_t *__res
         }
     }
     flush();
+}
+
+// distinct keys per key on a sample of the buckets hash_final_kernel is about to count: block i counts bucket
+// i * n_buckets / gridDim.x exactly (as many passes as its n asks for) -> dup[0] += distinct, dup[1] += n
+__global__ __launch_bounds__(1024) void hf_sample_kernel(const uint32_t *__restrict__ keys, const uint64_t *__restrict__ off,
+                                                         uint64_t n_buckets, int R, uint32_t log_t, unsigned long long *__restrict__ dup)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t hf_lds[];
+    __shared__ uint32_t sh_new;
+    uint32_t *tab = (uint32_t *)hf_lds;
+    const uint32_t T = 1u << log_t;
+    const uint64_t b = (uint64_t)blockIdx.x * n_buckets / gridDim.x;
+    const uint64_t s0 = off[b], n = off[b + 1] - s0;
+    if (threadIdx.x == 0)
+        sh_new = 0;
+    uint32_t lp = 0;
+    while (lp < (uint32_t)R && (n >> lp) > (uint64_t)(T / 8u * 5u))
+        lp++;
+    uint32_t fresh = 0;
+    for (uint32_t pass = 0; pass < (1u << lp); pass++) {
+        __syncthreads();
+        for (uint32_t q = threadIdx.x; q < T; q += 1024u)
+            tab[q] = 0;
+        __syncthreads();
+        for (uint64_t i = threadIdx.x; i < n; i += 1024u) {
+            const uint32_t key = keys[s0 + i];
+            if (lp && (key >> ((uint32_t)R - lp)) != pass)
+                continue;
+            uint32_t h = (key * 0x9E3779B1u) >> (32u - log_t);
+            const uint32_t mine = HF_VALID | (key << 11);
+            for (uint32_t tries = 0; tries < T; tries++) {
+                uint32_t e = tab[h];
+                if (e == 0u) {
+                    e = atomicCAS(&tab[h], 0u, mine);
+                    if (e == 0u) {
+                        fresh++;
+                        break;
+                    }
+                }
+                if (e == mine)
+                    break;
+                h = (h + 1u) & (T - 1u);
+            }
+        }
+    }
+    atomicAdd(&sh_new, fresh);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(dup, (unsigned long long)sh_new);
+        atomicAdd(dup + 1, (unsigned long long)n);
+    }
 }
 
 // ---- count spectrum without the u8 table (pcon::spectrum::Spectrum::from_count, src/main.rs:93) ----------------
@@ -1063,6 +1131,8 @@ namespace brx {
 
 struct PartState {
     Plan pl;
+    Plan pl_wide;     // the same first level, then the widest second digit (big inputs that end in hash_final_kernel)
+    bool use_wide = false; // which of the two the levels >= 2 of the finish in progress follow
     std::vector<PartBatch> batches, spare;
     // generic workspace
     uint32_t *d_ntiles = nullptr;      // per parent
@@ -1079,7 +1149,7 @@ struct PartState {
     uint64_t colpart_cap = 0;
     uint64_t *d_scan_tmp = nullptr;
     uint64_t scan_tmp_cap = 0;
-    unsigned long long *d_scalars = nullptr; // [0] n_items, [1] total keys of the last scan
+    unsigned long long *d_scalars = nullptr; // [0] n_items, [1] total keys of the last scan, [2..3] hf_sample_kernel
     uint64_t *d_coff[MAX_LEVELS] = {nullptr, nullptr, nullptr, nullptr}; // child offsets (nchild + 1)
     uint32_t *d_keys_mid = nullptr;    // outputs of the middle levels (ping-pong when there are 4 levels)
     uint64_t keys_mid_cap = 0;
@@ -1152,9 +1222,20 @@ int part_begin(brx_counter *c)
     c->part = st;
     st->pl = make_plan(c->k);
     const Plan &pl = st->pl;
-    hipError_t e = hipMalloc((void **)&st->d_scalars, 16);
-    for (int l = 0; l < pl.nlev && e == hipSuccess; l++)
-        e = hipMalloc((void **)&st->d_coff[l], (pl.nchild[l] + 1) * 8);
+    st->pl_wide = pl;
+    if (pl.nlev == 3 && pl.bits[1] < MAX_DIGIT_BITS) { // three levels: move bits from the last digit into the second
+        Plan &w = st->pl_wide;
+        const int moved = MAX_DIGIT_BITS - pl.bits[1] < pl.bits[2] ? MAX_DIGIT_BITS - pl.bits[1] : pl.bits[2];
+        w.bits[1] += moved;
+        w.bits[2] -= moved;
+        w.rem_in[2] -= moved;
+        w.nchild[1] <<= moved;
+    }
+    hipError_t e = hipMalloc((void **)&st->d_scalars, 32);
+    for (int l = 0; l < pl.nlev && e == hipSuccess; l++) {
+        const uint64_t nc = pl.nchild[l] > st->pl_wide.nchild[l] ? pl.nchild[l] : st->pl_wide.nchild[l];
+        e = hipMalloc((void **)&st->d_coff[l], (nc + 1) * 8);
+    }
     if (e == hipSuccess)
         e = hipMalloc((void **)&st->d_l1off_all, (pl.nchild[0] + 1) * 8);
     if (e == hipSuccess)
@@ -1343,7 +1424,7 @@ template <typename OUT>
 static int run_level(PartState *st, int l, const uint32_t *keys_in, const uint64_t *poff, uint64_t n_parents, uint64_t total,
                      void *keys_out, hipStream_t s, const char *tag_hist, const char *tag_scatter)
 {
-    const Plan &pl = st->pl;
+    const Plan &pl = st->use_wide ? st->pl_wide : st->pl;
     const uint32_t B = 1u << pl.bits[l];
     // 8192 keys per tile whatever the digit width: the (tile, digit) runs a scatter writes are then 32 keys = 128 bytes
     // on average instead of 64, and runs that straddle fewer lines cost fewer read-for-ownership fetches (level 2 of
@@ -1420,11 +1501,18 @@ static int run_level(PartState *st, int l, const uint32_t *keys_in, const uint64
 static int part_finish_impl(brx_counter *c, uint32_t abundance, hipStream_t s, brx_set *dst, unsigned long long *d_hist)
 {
     PartState *st = c->part;
-    const Plan &pl = st->pl;
-    const uint32_t B1 = (uint32_t)pl.nchild[0];
     uint64_t total = 0;
     for (auto &b : st->batches)
         total += b.n;
+    // Buckets that end in the LDS hash table (no bit vector to write) and would average more keys than one table pass
+    // takes even at high coverage: cut them finer at level 2 instead (k = 19: digits 9, 9 in place of 9, 8 -- 2^18
+    // buckets with 19 bits left; configs[3]'s share per GPU then has 24 000 keys per bucket, ~5 000 of them distinct)
+    static const bool wide_on = [] { const char *e = getenv("BRX_WIDE_L2"); return !(e && *e == '0'); }();
+    static const bool lazy_on = [] { const char *e = getenv("BRX_LAZY_BITS"); return !(e && *e == '0'); }();
+    st->use_wide = wide_on && !d_hist && dst && (dst->sparse || (index_wanted(c->k) && lazy_on)) && st->pl.nlev == 3 &&
+                   st->pl_wide.bits[1] != st->pl.bits[1] && total / st->pl.nchild[1] > 16384;
+    const Plan &pl = st->use_wide ? st->pl_wide : st->pl;
+    const uint32_t B1 = (uint32_t)pl.nchild[0];
 
     const uint32_t *keys1 = nullptr;
     const uint64_t *l1off = nullptr;
@@ -1474,7 +1562,6 @@ static int part_finish_impl(brx_counter *c, uint32_t abundance, hipStream_t s, b
     const bool emit = !d_hist && (dst->sparse || index_wanted(c->k));
     // lazy bit vector: when the solid hashes are listed anyway, the 2^(2k-4)-byte vector (16 GiB of slices at k = 19)
     // is written only if somebody asks for it later (ensure_bits); BRX_LAZY_BITS=0 writes it here as before
-    static const bool lazy_on = [] { const char *e = getenv("BRX_LAZY_BITS"); return !(e && *e == '0'); }();
     const bool lazy = emit && !dst->sparse && lazy_on;
     if (emit) {
         // (a set without bits has nothing but this list: it gets the exact bound)
@@ -1512,7 +1599,9 @@ static int part_finish_impl(brx_counter *c, uint32_t abundance, hipStream_t s, b
     static const bool hf_on = [] { const char *e = getenv("BRX_HASH_FINAL"); return !(e && *e == '0'); }();
     const int R_hf = pl.rem_in[pl.nlev - 1];
     const uint64_t nb_hf = pl.nlev >= 2 ? pl.nchild[pl.nlev - 2] : 0;
-    const bool hash_final = !d_hist && hf_on && (dst->sparse || lazy) && pl.nlev >= 3 && R_hf <= 20 && total / nb_hf <= 16384;
+    // (up to 2^17 keys per bucket: the table then takes a bucket in a few passes over its key range, see hash_final_kernel)
+    static const uint64_t hf_max_avg = [] { const char *e = getenv("BRX_HASH_FINAL_MAX"); return e && *e ? strtoull(e, nullptr, 10) : 131072ull; }();
+    const bool hash_final = !d_hist && hf_on && (dst->sparse || lazy) && pl.nlev >= 3 && R_hf <= 20 && total / nb_hf <= hf_max_avg;
     for (int l = 1; l < pl.nlev; l++) {
         if (hash_final && l == pl.nlev - 1)
             break;
@@ -1532,12 +1621,20 @@ static int part_finish_impl(brx_counter *c, uint32_t abundance, hipStream_t s, b
             const uint32_t log_t = 14;
             const size_t lds = ((size_t)4 << log_t) + hf_ebuf(1024) * 8 + 16;
             BRX_HIP(hipFuncSetAttribute((const void *)hash_final_kernel<1024, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            // buckets that would need passes by their key count: measure how many of the keys are distinct first
+            unsigned long long *dup = nullptr;
+            if (avg > (5ull << log_t) / 8ull / 2ull) {
+                dup = st->d_scalars + 2;
+                BRX_HIP(hipMemsetAsync(dup, 0, 16, s));
+                BRX_HIP(hipFuncSetAttribute((const void *)hf_sample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)4 << log_t)));
+                const int ns = (int)(nb_hf < 64ull ? nb_hf : 64ull);
+                hf_sample_kernel<<<ns, 1024, (size_t)4 << log_t, s>>>(kin, poff, nb_hf, R_hf, log_t, dup);
+            }
             const int grid = (int)(nb_hf < 256ull * 4ull ? nb_hf : 256ull * 4ull);
             hash_final_kernel<1024, 1024><<<grid, 1024, lds, s>>>(kin, poff, nb_hf, R_hf, abundance, log_t, dst->d_keylist, dst->keylist_cap,
-                                                          dst->d_keylist_n);
-        } else { // one wave per bucket; table of 256..2048 entries, about 4x the average bucket (the clear and the
-                 // scan of the table cost every bucket T / 64 LDS accesses per lane each, its keys only n / 64)
-            // (k = 21 at 1 Gbp, 119 keys per bucket: 512 entries, 6.1 ms; with 2048 it was 17.1 ms; 2x or 3x room measure the same)
+                                                          dst->d_keylist_n, dup);
+        } else { // one wave per bucket; table of 256..2048 entries, about 4x the average bucket (clearing the table costs
+                 // every bucket T / 256 LDS stores per lane, its keys n / 64 inserts)
             uint32_t log_t = 8;
             while (log_t < 11 && (1ull << log_t) < 4 * avg)
                 log_t++;
@@ -1545,7 +1642,7 @@ static int part_finish_impl(brx_counter *c, uint32_t abundance, hipStream_t s, b
             const uint64_t want = (nb_hf + 3) / 4;
             const int grid = (int)(want < 256ull * 16ull ? want : 256ull * 16ull);
             hash_final_kernel<64, 256><<<grid, 256, lds, s>>>(kin, poff, nb_hf, R_hf, abundance, log_t, dst->d_keylist, dst->keylist_cap,
-                                                         dst->d_keylist_n);
+                                                         dst->d_keylist_n, nullptr);
         }
         BRX_HIP(hipGetLastError());
         trace_stage(s, "hash final");

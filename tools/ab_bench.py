@@ -2,7 +2,7 @@
 """Same-box A/B of library variants (tools/ab_build.sh): runs bench.py once per variant per round, interleaved, and prints the
 per-kernel averages side by side.  Boxes of the pool differ by up to ~10 % on identical code; only numbers from one call compare.
 
-    python tools/ab_bench.py [--rounds 2] [--steps 10] [--config 1] default nor0 noxcd ...
+    python tools/ab_bench.py [--rounds 2] [--steps 10] [--config 1] [--env tag:KEY=VALUE] default base default+tag ...
 """
 import argparse
 import json
@@ -19,7 +19,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=2)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--config", type=int, default=1)
-    ap.add_argument("--env", action="append", default=[], help="NAME:KEY=VALUE sets an environment variable for variant NAME")
+    ap.add_argument("--env", action="append", default=[], help="TAG:KEY=VALUE sets an environment variable for the variants named LIB+TAG")
     args = ap.parse_args()
     extra = {}
     for e in args.env:
@@ -33,7 +33,8 @@ def main():
             lib = v.split("+")[0]
             if lib != "default":
                 env["BRX_LIB_PATH"] = os.path.join(ROOT, "br_amd", "lib", "ab", f"libbrx_{lib}.so")
-            env.update(extra.get(v, {}))
+            for tag in v.split("+")[1:]:  # "default+nowide" = the default library with the variables given as --env nowide:K=V
+                env.update(extra[tag])
             out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", str(args.steps), "--warmup", "2",
                                   "--config", str(args.config), "--no-cpu-baseline", "--no-e2e"], env=env, capture_output=True, text=True)
             line = [l for l in out.stdout.splitlines() if l.startswith("{")]
@@ -56,7 +57,7 @@ def main():
         print(f"{ph:28s}" + "".join(f"{min(d['phases'][ph] for d in rows[v]):14.3f}" if rows[v] else f"{'-':>14s}" for v in args.variants))
     for k in kernels:
         print(f"{k:28s}" + "".join(
-            f"{min(d['kernels'][k]['avg_ms'] * d['kernels'][k]['launches'] / d['steps'] for d in rows[v] if k in d['kernels']):14.3f}"
+            f"{min([d['kernels'][k]['avg_ms'] * d['kernels'][k]['launches'] / d['steps'] for d in rows[v] if k in d['kernels']] or [float('nan')]):14.3f}"
             if rows[v] else f"{'-':>14s}" for v in args.variants))
 
 
