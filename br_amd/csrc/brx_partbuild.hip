@@ -870,11 +870,12 @@ __global__ __launch_bounds__(BLOCK) void hash_final_kernel(const uint32_t *__res
     extern __shared__ __attribute__((aligned(16))) uint8_t hf_lds[];
     constexpr int TEAMS = BLOCK / TEAM;
     constexpr uint32_t EB = hf_ebuf(TEAM);
-    const uint32_t T = 1u << log_t;
+    constexpr uint32_t MIN_LT = TEAM > 64 ? 12u : 8u; // a table is cleared 4 slots per lane and step: at least 4 * TEAM slots
+    const uint32_t Tmax = 1u << log_t;
     const int team = threadIdx.x / TEAM, tl = threadIdx.x % TEAM;
-    uint32_t *tab = (uint32_t *)hf_lds + (size_t)team * T;
-    unsigned long long *ebuf = (unsigned long long *)(hf_lds + (size_t)TEAMS * T * 4) + (size_t)team * EB;
-    uint32_t *ctl = (uint32_t *)(hf_lds + (size_t)TEAMS * T * 4 + (size_t)TEAMS * EB * 8) + team * 4; // [0] ecount, [1] overflow
+    uint32_t *tab = (uint32_t *)hf_lds + (size_t)team * Tmax;
+    unsigned long long *ebuf = (unsigned long long *)(hf_lds + (size_t)TEAMS * Tmax * 4) + (size_t)team * EB;
+    uint32_t *ctl = (uint32_t *)(hf_lds + (size_t)TEAMS * Tmax * 4 + (size_t)TEAMS * EB * 8) + team * 4; // [0] ecount, [1] overflow
     auto team_sync = [&]() {
         if (TEAM > 64)
             __syncthreads();
@@ -917,8 +918,18 @@ __global__ __launch_bounds__(BLOCK) void hash_final_kernel(const uint32_t *__res
         // passes: 2^lp disjoint ranges of the R-bit key, each expected to bring <= 5/8 T DISTINCT keys
         const uint64_t n_eff = (uint64_t)((float)n * ratio) + 1ull;
         uint32_t lp = 0;
-        while (lp < (uint32_t)R && (n_eff >> lp) > (uint64_t)(T / 8u * 5u))
+        while (lp < (uint32_t)R && (n_eff >> lp) > (uint64_t)(Tmax / 8u * 5u))
             lp++;
+        // the table of THIS bucket: 2.5 slots per distinct key expected, not the launch's maximum -- clearing and scanning
+        // cost T / TEAM LDS accesses per lane whatever the bucket holds (k = 21: 745 keys, ~200 distinct, in 2048 slots)
+        uint32_t lt = log_t;
+        if (lp == 0) {
+            const uint32_t want = (uint32_t)n_eff * 5u / 2u;
+            lt = MIN_LT < log_t ? MIN_LT : log_t;
+            while (lt < log_t && (1u << lt) < want)
+                lt++;
+        }
+        uint32_t T = 1u << lt;
         for (uint32_t pass = 0; pass < (1u << lp);) {
             for (uint32_t q = tl * 4u; q < T; q += TEAM * 4u) // 16 bytes per lane and store (T >= 4 * TEAM)
                 *(uint4 *)(tab + q) = make_uint4(0u, 0u, 0u, 0u);
@@ -936,7 +947,7 @@ __global__ __launch_bounds__(BLOCK) void hash_final_kernel(const uint32_t *__res
                 const uint32_t key = kbuf[c];
                 if (key == 0xffffffffu || (lp && (key >> ((uint32_t)R - lp)) != pass))
                     continue;
-                uint32_t h = (key * 0x9E3779B1u) >> (32u - log_t);
+                uint32_t h = (key * 0x9E3779B1u) >> (32u - lt);
                 const uint32_t mine = HF_VALID | (key << 11);
                 for (uint32_t tries = 0;; tries++) {
                     uint32_t e = tab[h];
@@ -961,10 +972,15 @@ __global__ __launch_bounds__(BLOCK) void hash_final_kernel(const uint32_t *__res
             team_sync();
             const uint32_t ovf = ctl[1];
             team_sync();
-            if (ovf) { // redo this key range in 4 finer passes
+            if (ovf) { // redo this key range: with the whole table if it had less, else in 4 finer passes
                 if (tl == 0)
                     ctl[1] = 0;
                 team_sync();
+                if (lt < log_t) {
+                    lt = log_t;
+                    T = Tmax;
+                    continue;
+                }
                 if (lp + 2u <= (uint32_t)R) {
                     lp += 2u;
                     pass <<= 2;
@@ -1617,24 +1633,25 @@ static int part_finish_impl(brx_counter *c, uint32_t abundance, hipStream_t s, b
     if (hash_final) {
         KernelTimer t("part_hash_final", s);
         const uint64_t avg = total / nb_hf;
+        // how many of a bucket's keys are distinct, measured on 64 buckets: sizes each bucket's table and passes
+        unsigned long long *dup = st->d_scalars + 2;
+        {
+            BRX_HIP(hipMemsetAsync(dup, 0, 16, s));
+            BRX_HIP(hipFuncSetAttribute((const void *)hf_sample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+            const int ns = (int)(nb_hf < 64ull ? nb_hf : 64ull);
+            hf_sample_kernel<<<ns, 1024, 65536, s>>>(kin, poff, nb_hf, R_hf, 14, dup);
+        }
         if (avg > 640) { // one 1024-thread workgroup per bucket, 16384-entry table
             const uint32_t log_t = 14;
             const size_t lds = ((size_t)4 << log_t) + hf_ebuf(1024) * 8 + 16;
             BRX_HIP(hipFuncSetAttribute((const void *)hash_final_kernel<1024, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            // buckets that would need passes by their key count: measure how many of the keys are distinct first
-            unsigned long long *dup = nullptr;
-            if (avg > (5ull << log_t) / 8ull / 2ull) {
-                dup = st->d_scalars + 2;
-                BRX_HIP(hipMemsetAsync(dup, 0, 16, s));
-                BRX_HIP(hipFuncSetAttribute((const void *)hf_sample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)4 << log_t)));
-                const int ns = (int)(nb_hf < 64ull ? nb_hf : 64ull);
-                hf_sample_kernel<<<ns, 1024, (size_t)4 << log_t, s>>>(kin, poff, nb_hf, R_hf, log_t, dup);
-            }
             const int grid = (int)(nb_hf < 256ull * 4ull ? nb_hf : 256ull * 4ull);
             hash_final_kernel<1024, 1024><<<grid, 1024, lds, s>>>(kin, poff, nb_hf, R_hf, abundance, log_t, dst->d_keylist, dst->keylist_cap,
                                                           dst->d_keylist_n, dup);
-        } else { // one wave per bucket; table of 256..2048 entries, about 4x the average bucket (clearing the table costs
-                 // every bucket T / 256 LDS stores per lane, its keys n / 64 inserts)
+        } else { // one wave per bucket; at most 256..2048 table entries, about 4x the average bucket (each bucket then uses
+                 // 2.5 slots per distinct key expected: clearing and scanning cost T / 256 LDS accesses per lane).  Sizing
+                 // the launch's maximum from the sampled ratio as well (1024 slots = 6 workgroups per CU instead of 3)
+                 // measured the same 66.9 ms at configs[4]'s share: the kernel is not short of waves.
             uint32_t log_t = 8;
             while (log_t < 11 && (1ull << log_t) < 4 * avg)
                 log_t++;
@@ -1642,7 +1659,7 @@ static int part_finish_impl(brx_counter *c, uint32_t abundance, hipStream_t s, b
             const uint64_t want = (nb_hf + 3) / 4;
             const int grid = (int)(want < 256ull * 16ull ? want : 256ull * 16ull);
             hash_final_kernel<64, 256><<<grid, 256, lds, s>>>(kin, poff, nb_hf, R_hf, abundance, log_t, dst->d_keylist, dst->keylist_cap,
-                                                         dst->d_keylist_n, nullptr);
+                                                         dst->d_keylist_n, dup);
         }
         BRX_HIP(hipGetLastError());
         trace_stage(s, "hash final");
