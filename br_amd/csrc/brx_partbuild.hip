@@ -213,6 +213,44 @@ __device__ __forceinline__ bool l1_valid(const uint32_t *bnd, uint32_t p, int k)
     return bits == 0u;
 }
 
+// Every valid k-mer of the tile, rolled: thread t takes window positions 16t .. 16t+15 (L1_TILE = 256 x 16), builds the
+// first k-mer and its reverse complement once and then shifts one base in per step -- f(canonical hash) -- instead of
+// cutting every k-mer out of pk[] (three LDS reads, a funnel shift, a 64-bit bit reversal) and testing the boundary
+// bitmap with two more LDS reads per position.  Both level-1 kernels are bound by the instructions they issue.
+static_assert(L1_TILE == 256u * 16u, "l1_for_each_hash: 16 positions per thread");
+template <typename F>
+__device__ __forceinline__ void l1_for_each_hash(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ bnd, uint32_t n_here,
+                                                 int k, F &&f)
+{
+    const uint32_t p0 = threadIdx.x * 16u;
+    if (p0 >= n_here)
+        return;
+    const uint32_t w = threadIdx.x; // p0 / 16
+    const uint64_t hi = ((uint64_t)pk[w] << 32) | pk[w + 1];
+    const uint64_t lo = pk[w + 2];
+    const uint64_t mask = kmask(k);
+    uint64_t fwd = hi >> (64 - 2 * k);
+    uint64_t rc = revcomp(fwd, k);
+    // the bases behind the first k-mer, the next one in the top two bits (the 96-bit string hi:lo shifted left by 2k)
+    uint64_t next = (hi << (2 * k)) | (2 * k >= 32 ? lo << (2 * k - 32) : lo >> (32 - 2 * k));
+    // bit i = a read starts at window position p0 + 1 + i; position p0 + j is valid iff bits j .. j + k - 2 are clear
+    const uint32_t q = p0 + 1u, wq = q >> 5, sh = q & 31u;
+    uint64_t vb = ((((uint64_t)bnd[wq + 1] << 32) | bnd[wq]) >> sh) | (sh ? (uint64_t)bnd[wq + 2] << (64u - sh) : 0ull);
+    const uint64_t vmask = k > 1 ? (1ull << (k - 1)) - 1ull : 0ull;
+    const uint32_t left = n_here - p0 < 16u ? n_here - p0 : 16u;
+    const int top = 2 * k - 2;
+#pragma unroll 4
+    for (uint32_t j = 0; j < left; j++) {
+        if ((vb & vmask) == 0ull)
+            f(((popc64(fwd) & 1) ? rc : fwd) >> 1);
+        const uint64_t b = next >> 62;
+        next <<= 2;
+        vb >>= 1;
+        fwd = ((fwd << 2) | b) & mask;
+        rc = (rc >> 2) | ((b ^ 2ull) << top);
+    }
+}
+
 __global__ __launch_bounds__(256) void l1_hist_kernel(L1Args a)
 {
     extern __shared__ uint32_t lds[]; // hist[B]
@@ -227,9 +265,7 @@ __global__ __launch_bounds__(256) void l1_hist_kernel(L1Args a)
             lds[b] = 0;
         uint32_t n_here;
         l1_prepare(a, item, pk, bnd, &sh_r0, n_here);
-        for (uint32_t p = threadIdx.x; p < n_here; p += 256)
-            if (l1_valid(bnd, p, a.k))
-                atomicAdd(&lds[(uint32_t)(khash(kmer_at(pk, p, a.k), a.k) >> shift)], 1u);
+        l1_for_each_hash(pk, bnd, n_here, a.k, [&](uint64_t h) { atomicAdd(&lds[(uint32_t)(h >> shift)], 1u); });
         __syncthreads();
         for (uint32_t b = threadIdx.x; b < B; b += 256)
             a.matrix[(uint64_t)item * B + b] = lds[b];
@@ -431,14 +467,12 @@ __global__ __launch_bounds__(256) void l1_scatter_kernel(L1Args a)
         l1_prepare(a, item, pk, bnd, &sh_r0, n_here);
         block_scan_bins(B, cntv, lofs, lcur, sh_wsum);
         __syncthreads();
-        for (uint32_t p = threadIdx.x; p < n_here; p += 256)
-            if (l1_valid(bnd, p, a.k)) {
-                const uint64_t h = khash(kmer_at(pk, p, a.k), a.k);
-                const uint32_t d = (uint32_t)(h >> shift);
-                const uint32_t slot = atomicAdd(&lcur[d], 1u);
-                stage_key[slot] = (uint32_t)(h & child_mask);
-                stage_dig[slot] = (uint16_t)d;
-            }
+        l1_for_each_hash(pk, bnd, n_here, a.k, [&](uint64_t h) {
+            const uint32_t d = (uint32_t)(h >> shift);
+            const uint32_t slot = atomicAdd(&lcur[d], 1u);
+            stage_key[slot] = (uint32_t)(h & child_mask);
+            stage_dig[slot] = (uint16_t)d;
+        });
         __syncthreads();
         const uint32_t n_tile = lofs[B - 1] + cntv[B - 1];
         for (uint32_t idx = threadIdx.x; idx < n_tile; idx += 256) {
