@@ -899,12 +899,12 @@ __global__ __launch_bounds__(BLOCK) void hash_final_kernel(const uint32_t *__res
                                                          uint64_t n_buckets, int R, uint32_t abundance, uint32_t log_t,
                                                          uint64_t *__restrict__ emit_keys, uint64_t emit_cap,
                                                          unsigned long long *__restrict__ emit_n,
-                                                         const unsigned long long *__restrict__ dup)
+                                                         const unsigned long long *__restrict__ dup, uint32_t min_lt, float ratio_forced)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t hf_lds[];
     constexpr int TEAMS = BLOCK / TEAM;
     constexpr uint32_t EB = hf_ebuf(TEAM);
-    constexpr uint32_t MIN_LT = TEAM > 64 ? 12u : 8u; // a table is cleared 4 slots per lane and step: at least 4 * TEAM slots
+    const uint32_t MIN_LT = min_lt; // smallest table a bucket gets (hf_min_lt: 4 slots per lane and clearing step)
     const uint32_t Tmax = 1u << log_t;
     const int team = threadIdx.x / TEAM, tl = threadIdx.x % TEAM;
     uint32_t *tab = (uint32_t *)hf_lds + (size_t)team * Tmax;
@@ -944,6 +944,8 @@ __global__ __launch_bounds__(BLOCK) void hash_final_kernel(const uint32_t *__res
         if (t > 0.0f)
             ratio = fminf(1.0f, 1.25f * d / t + 0.01f);
     }
+    if (ratio_forced > 0.0f) // test hook (BRX_HF_RATIO): a wrong guess must only cost time
+        ratio = ratio_forced;
     const uint64_t n_teams = (uint64_t)gridDim.x * TEAMS;
     for (uint64_t b = (uint64_t)blockIdx.x * TEAMS + team; b < n_buckets; b += n_teams) { // (team-uniform trip count)
         const uint64_t s0 = off[b], n = off[b + 1] - s0;
@@ -1667,6 +1669,11 @@ static int part_finish_impl(brx_counter *c, uint32_t abundance, hipStream_t s, b
     if (hash_final) {
         KernelTimer t("part_hash_final", s);
         const uint64_t avg = total / nb_hf;
+        // test hooks, read per call: BRX_HF_LOG_T = the launch's table maximum (log2), BRX_HF_MIN_LT = the smallest table a
+        // bucket gets, BRX_HF_RATIO = the share of distinct keys to assume instead of the sampled one.  Small or wrongly
+        // guessed tables walk the whole ladder (bigger table -> 4x finer passes) on inputs a test can afford.
+        const char *e_logt = getenv("BRX_HF_LOG_T"), *e_minlt = getenv("BRX_HF_MIN_LT"), *e_ratio = getenv("BRX_HF_RATIO");
+        const float ratio_forced = e_ratio && *e_ratio ? (float)atof(e_ratio) : 0.0f;
         // how many of a bucket's keys are distinct, measured on 64 buckets: sizes each bucket's table and passes
         unsigned long long *dup = st->d_scalars + 2;
         {
@@ -1676,12 +1683,15 @@ static int part_finish_impl(brx_counter *c, uint32_t abundance, hipStream_t s, b
             hf_sample_kernel<<<ns, 1024, 65536, s>>>(kin, poff, nb_hf, R_hf, 14, dup);
         }
         if (avg > 640) { // one 1024-thread workgroup per bucket, 16384-entry table
-            const uint32_t log_t = 14;
+            uint32_t log_t = 14;
+            if (e_logt && *e_logt && atoi(e_logt) >= 6 && atoi(e_logt) <= 14)
+                log_t = (uint32_t)atoi(e_logt);
+            const uint32_t min_lt = e_minlt && *e_minlt && atoi(e_minlt) >= 4 ? (uint32_t)atoi(e_minlt) : 12u;
             const size_t lds = ((size_t)4 << log_t) + hf_ebuf(1024) * 8 + 16;
             BRX_HIP(hipFuncSetAttribute((const void *)hash_final_kernel<1024, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             const int grid = (int)(nb_hf < 256ull * 4ull ? nb_hf : 256ull * 4ull);
             hash_final_kernel<1024, 1024><<<grid, 1024, lds, s>>>(kin, poff, nb_hf, R_hf, abundance, log_t, dst->d_keylist, dst->keylist_cap,
-                                                          dst->d_keylist_n, dup);
+                                                          dst->d_keylist_n, dup, min_lt, ratio_forced);
         } else { // one wave per bucket; at most 256..2048 table entries, about 4x the average bucket (each bucket then uses
                  // 2.5 slots per distinct key expected: clearing and scanning cost T / 256 LDS accesses per lane).  Sizing
                  // the launch's maximum from the sampled ratio as well (1024 slots = 6 workgroups per CU instead of 3)
@@ -1689,11 +1699,14 @@ static int part_finish_impl(brx_counter *c, uint32_t abundance, hipStream_t s, b
             uint32_t log_t = 8;
             while (log_t < 11 && (1ull << log_t) < 4 * avg)
                 log_t++;
+            if (e_logt && *e_logt && atoi(e_logt) >= 6 && atoi(e_logt) <= 11)
+                log_t = (uint32_t)atoi(e_logt);
+            const uint32_t min_lt = e_minlt && *e_minlt && atoi(e_minlt) >= 4 ? (uint32_t)atoi(e_minlt) : 8u;
             const size_t lds = 4 * (((size_t)4 << log_t) + hf_ebuf(64) * 8 + 16);
             const uint64_t want = (nb_hf + 3) / 4;
             const int grid = (int)(want < 256ull * 16ull ? want : 256ull * 16ull);
             hash_final_kernel<64, 256><<<grid, 256, lds, s>>>(kin, poff, nb_hf, R_hf, abundance, log_t, dst->d_keylist, dst->keylist_cap,
-                                                         dst->d_keylist_n, dup);
+                                                         dst->d_keylist_n, dup, min_lt, ratio_forced);
         }
         BRX_HIP(hipGetLastError());
         trace_stage(s, "hash final");

@@ -183,13 +183,22 @@ def test_more_than_2_31_kmers_in_one_counter():
     assert kl is not None and kl[1] == n_solid
 
 
-def test_hash_final_skewed_buckets():
-    """the LDS hash-count of the partitioned finish on hand-made keys (fed through the exchange entry
+@pytest.mark.parametrize("hooks", [
+    {},
+    {"BRX_HF_RATIO": "0.01"},                                            # "hardly any key is distinct": every table starts too small
+    {"BRX_HF_LOG_T": "10", "BRX_HF_MIN_LT": "6"},                        # 1024-slot tables: most buckets need passes
+    {"BRX_HF_RATIO": "0.01", "BRX_HF_LOG_T": "8", "BRX_HF_MIN_LT": "4"},  # 256 slots and a wrong guess: the whole ladder
+], ids=["default", "ratio_0.01", "tables_1024", "tables_256_ratio_0.01"])
+def test_hash_final_skewed_buckets(hooks, monkeypatch):
+    """(hooks: the table-sizing test switches of part_finish_impl, read per call -- a wrong guess of the share of distinct
+    keys or a small table must only cost passes.)  The LDS hash-count of the partitioned finish on hand-made keys (fed through the exchange entry
     add_partitioned_device): one level-2 bucket with 40 000 DISTINCT hashes that all fall into the first quarter of
     its key range (more than the table holds: the pass is redone on finer ranges, and the solid hashes outnumber the
     workgroup's list buffer), a bucket with one hash repeated 300 000 times (many passes, a saturated count), and a
     sprinkle of ordinary keys.  Checked against the counts computed on the host."""
     import torch
+    for name, val in hooks.items():
+        monkeypatch.setenv(name, val)
     k = 19
     stream = torch.cuda.current_stream().cuda_stream
     rng = np.random.default_rng(11)
