@@ -1,6 +1,6 @@
 // Host pipeline of run_correction (src/lib.rs:22-139) and of count_fasta (src/main.rs:72-78) over file
-// descriptors: FASTA parse -> pinned batch -> H2D -> kernels -> D2H -> FASTA format -> write, the three stages
-// on their own threads so that parsing, the GPU and formatting of consecutive batches overlap.
+// descriptors: FASTA parse -> pinned batch -> H2D -> kernels -> FASTA text made on the device -> D2H -> write, the
+// three stages on their own threads so that parsing, the GPU and the writes of consecutive batches overlap.
 //
 // FASTA conventions = noodles::fasta::{Reader, Writer} as the reference uses them (src/lib.rs:30-31,57-60,
 // 80-81,123-131; noodles-fasta 0.38, not vendored, UNPINNED by the reference's tests), the same rules as
@@ -21,6 +21,8 @@
 #include <string.h>
 #include <unistd.h>
 #include <poll.h>
+#include <fcntl.h>
+#include <sys/stat.h>
 
 using namespace brx;
 
@@ -41,7 +43,7 @@ inline uint64_t batch_bases()
     }();
     return v;
 }
-constexpr int N_SLOTS = 5;
+constexpr int N_SLOTS = 6;
 
 inline bool is_ws(unsigned char c) { return c == ' ' || c == '\t' || c == '\n' || c == '\r' || c == '\v' || c == '\f'; }
 
@@ -93,28 +95,6 @@ struct Pinned {
     }
 };
 
-// growable byte buffer without value-initialisation (a std::vector resize would zero 140 MB per batch first)
-struct RawBuf {
-    char *p = nullptr;
-    size_t cap = 0, len = 0;
-    bool reserve(size_t need)
-    {
-        if (need <= cap)
-            return true;
-        free(p);
-        cap = 0;
-        p = (char *)malloc(need + need / 8);
-        if (!p)
-            return false;
-        cap = need + need / 8;
-        return true;
-    }
-    RawBuf() = default;
-    RawBuf(const RawBuf &) = delete;
-    RawBuf &operator=(const RawBuf &) = delete;
-    ~RawBuf() { free(p); }
-};
-
 struct Batch {
     uint64_t seq = 0;             // position in the stream (the writer emits in this order)
     Pinned bases;                 // concatenated sequences
@@ -122,9 +102,9 @@ struct Batch {
     std::string defs;             // re-emitted definition lines, concatenated
     std::vector<uint32_t> def_end; // end offset of record r's definition in `defs`
     uint64_t total = 0;
-    Pinned out;                   // corrected bases
-    std::vector<uint64_t> out_offsets;
-    RawBuf text;                  // the batch as FASTA text (filled by the GPU worker that corrected it)
+    Pinned text;                  // the batch as FASTA text, formatted on the GPU and copied here by the worker that corrected it
+    uint64_t text_len = 0;
+    uint64_t out_total = 0;       // corrected bases of the batch
     bool last = false;
     void clear()
     {
@@ -436,6 +416,86 @@ int write_all(int fd, const char *p, size_t n)
     return BRX_OK;
 }
 
+// ---- the writer's text, made on the device ------------------------------------------------------------------------------
+// noodles' fasta::Writer layout (see the top of the file): '>' definition '\n', then the sequence in lines of 80.  The
+// host used to build it with one 80-byte memcpy per line (0.36 s per Gbp over two threads, more than the kernels of the
+// batch); here a batch costs the host one prefix-sum read-back and the D2H copy it needed anyway, 1.25 % longer.
+// text_off[r] = where record r starts in the text; text_off[n] = its length.  One block: every thread sums a
+// contiguous run of records, the runs are scanned through LDS.
+__global__ __launch_bounds__(1024) void text_offsets_kernel(const uint64_t *__restrict__ out_off, const uint32_t *__restrict__ def_end,
+                                                            uint32_t n, uint64_t *__restrict__ text_off)
+{
+    __shared__ uint64_t run_sum[1024];
+    const uint32_t per = (n + 1023u) / 1024u;
+    const uint32_t r0 = threadIdx.x * per, r1 = r0 + per < n ? r0 + per : n;
+    auto size_of = [&](uint32_t r) -> uint64_t {
+        const uint64_t len = out_off[r + 1] - out_off[r];
+        const uint64_t dl = def_end[r] - (r ? def_end[r - 1] : 0u);
+        return 2ull + dl + len + (len + LINE_BASES - 1) / LINE_BASES;
+    };
+    uint64_t mine = 0;
+    for (uint32_t r = r0; r < r1; r++)
+        mine += size_of(r);
+    run_sum[threadIdx.x] = mine;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024u; d <<= 1) { // inclusive scan
+        const uint64_t v = threadIdx.x >= d ? run_sum[threadIdx.x - d] : 0ull;
+        __syncthreads();
+        run_sum[threadIdx.x] += v;
+        __syncthreads();
+    }
+    uint64_t run = run_sum[threadIdx.x] - mine;
+    for (uint32_t r = r0; r < r1; r++) {
+        text_off[r] = run;
+        run += size_of(r);
+    }
+    if (threadIdx.x == 1023)
+        text_off[n] = run_sum[1023];
+}
+
+// one workgroup per record (grid-stride)
+__global__ __launch_bounds__(256) void format_kernel(const uint8_t *__restrict__ seqs, const uint64_t *__restrict__ out_off,
+                                                     const uint8_t *__restrict__ defs, const uint32_t *__restrict__ def_end,
+                                                     const uint64_t *__restrict__ text_off, uint32_t n, uint8_t *__restrict__ text)
+{
+    for (uint32_t r = blockIdx.x; r < n; r += gridDim.x) {
+        const uint32_t d0 = r ? def_end[r - 1] : 0u, dl = def_end[r] - d0;
+        uint8_t *w = text + text_off[r];
+        if (threadIdx.x == 0) {
+            w[0] = '>';
+            w[1 + dl] = '\n';
+        }
+        for (uint32_t i = threadIdx.x; i < dl; i += 256)
+            w[1 + i] = defs[d0 + i];
+        w += 2 + dl;
+        const uint8_t *seq = seqs + out_off[r];
+        const uint64_t len = out_off[r + 1] - out_off[r];
+        const uint64_t tl = len + (len + LINE_BASES - 1) / LINE_BASES;
+        for (uint64_t j = threadIdx.x; j < tl; j += 256) {
+            const uint64_t line = j / (LINE_BASES + 1), col = j - line * (LINE_BASES + 1);
+            const uint64_t src = line * LINE_BASES + col;
+            w[j] = (col == LINE_BASES || src >= len) ? (uint8_t)'\n' : seq[src];
+        }
+    }
+}
+
+int pwrite_all(int fd, const char *p, size_t n, uint64_t off)
+{
+    while (n) {
+        ssize_t w = ::pwrite(fd, p, n, (off_t)off);
+        if (w < 0) {
+            if (errno == EINTR)
+                continue;
+            set_error("pwrite: %s", strerror(errno));
+            return BRX_ERR_ARG;
+        }
+        p += w;
+        n -= (size_t)w;
+        off += (uint64_t)w;
+    }
+    return BRX_OK;
+}
+
 struct Shared {
     std::mutex mu;
     int status = BRX_OK;
@@ -460,6 +520,44 @@ struct DevBufs {
     uint8_t *d_in = nullptr, *d_out = nullptr;
     uint64_t *d_off = nullptr, *d_out_off = nullptr;
     uint64_t in_cap = 0, out_cap = 0, off_cap = 0;
+    // the FASTA text of the batch (format_kernel): definitions, their ends, record starts, the text
+    uint8_t *d_defs = nullptr, *d_text = nullptr;
+    uint32_t *d_def_end = nullptr;
+    uint64_t *d_text_off = nullptr;
+    uint64_t defs_cap = 0, text_cap = 0, tmeta_cap = 0;
+    int ensure_text_meta(uint64_t defs_bytes, uint32_t n)
+    {
+        if (defs_bytes + 1 > defs_cap) {
+            if (d_defs)
+                (void)hipFree(d_defs);
+            d_defs = nullptr;
+            defs_cap = defs_bytes + defs_bytes / 4 + 4096;
+            BRX_HIP(hipMalloc((void **)&d_defs, defs_cap));
+        }
+        if ((uint64_t)n + 1 > tmeta_cap) {
+            if (d_def_end)
+                (void)hipFree(d_def_end);
+            if (d_text_off)
+                (void)hipFree(d_text_off);
+            d_def_end = nullptr;
+            d_text_off = nullptr;
+            tmeta_cap = (uint64_t)n + n / 8 + 64;
+            BRX_HIP(hipMalloc((void **)&d_def_end, tmeta_cap * 4));
+            BRX_HIP(hipMalloc((void **)&d_text_off, tmeta_cap * 8));
+        }
+        return BRX_OK;
+    }
+    int ensure_text(uint64_t bytes)
+    {
+        if (bytes + 64 > text_cap) {
+            if (d_text)
+                (void)hipFree(d_text);
+            d_text = nullptr;
+            text_cap = bytes + bytes / 8 + 4096;
+            BRX_HIP(hipMalloc((void **)&d_text, text_cap));
+        }
+        return BRX_OK;
+    }
     int ensure(uint64_t bases, uint32_t n)
     {
         if (bases + 64 > in_cap) {
@@ -499,13 +597,17 @@ struct DevBufs {
             (void)hipFree(d_off);
         if (d_out_off)
             (void)hipFree(d_out_off);
+        for (void *q : {(void *)d_defs, (void *)d_text, (void *)d_def_end, (void *)d_text_off})
+            if (q)
+                (void)hipFree(q);
     }
 };
 
 int correct_one_batch(brx_chain_t *chain, DevBufs &dv, hipStream_t s, Batch &b)
 {
     const uint32_t n = b.n();
-    b.out_offsets.assign((size_t)n + 1, 0);
+    b.text_len = 0;
+    b.out_total = 0;
     if (n == 0)
         return BRX_OK;
     const bool tr = pipe_trace();
@@ -530,59 +632,30 @@ int correct_one_batch(brx_chain_t *chain, DevBufs &dv, hipStream_t s, Batch &b)
                                             &out_total, s);
     }
     BRX_TRY(st);
+    b.out_total = out_total;
     const double t3 = now_s();
-    BRX_TRY(b.out.reserve(out_total + 64, 0));
-    const double t4 = now_s();
-    if (out_total)
-        BRX_HIP(hipMemcpyAsync(b.out.p, dv.d_out, out_total, hipMemcpyDeviceToHost, s));
-    BRX_HIP(hipMemcpyAsync(b.out_offsets.data(), dv.d_out_off, ((size_t)n + 1) * 8, hipMemcpyDeviceToHost, s));
+    // the FASTA text, on the device: record starts from the corrected lengths and the definitions' lengths, then the text
+    BRX_TRY(dv.ensure_text_meta(b.defs.size(), n));
+    if (!b.defs.empty())
+        BRX_HIP(hipMemcpyAsync(dv.d_defs, b.defs.data(), b.defs.size(), hipMemcpyHostToDevice, s));
+    BRX_HIP(hipMemcpyAsync(dv.d_def_end, b.def_end.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
+    text_offsets_kernel<<<1, 1024, 0, s>>>(dv.d_out_off, dv.d_def_end, n, dv.d_text_off);
+    uint64_t text_len = 0;
+    BRX_HIP(hipMemcpyAsync(&text_len, dv.d_text_off + n, 8, hipMemcpyDeviceToHost, s));
     BRX_HIP(hipStreamSynchronize(s));
+    BRX_TRY(dv.ensure_text(text_len));
+    BRX_TRY(b.text.reserve(text_len + 64, 0));
+    const double t4 = now_s();
+    format_kernel<<<n < 4096u ? n : 4096u, 256, 0, s>>>(dv.d_out, dv.d_out_off, dv.d_defs, dv.d_def_end, dv.d_text_off, n, dv.d_text);
+    BRX_HIP(hipGetLastError());
+    if (text_len)
+        BRX_HIP(hipMemcpyAsync(b.text.p, dv.d_text, text_len, hipMemcpyDeviceToHost, s));
+    BRX_HIP(hipStreamSynchronize(s));
+    b.text_len = text_len;
     if (tr)
-        fprintf(stderr, "[brx pipe] batch %llu (%u records, %.1f MB): dev alloc %.2f, h2d %.2f, correct %.2f, pinned out %.2f, d2h %.2f ms\n",
+        fprintf(stderr, "[brx pipe] batch %llu (%u records, %.1f MB): dev alloc %.2f, h2d %.2f, correct %.2f, text offsets + buffers %.2f, format + d2h %.2f ms\n",
                 (unsigned long long)b.seq, n, (double)b.total / 1e6, (t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3, (t4 - t3) * 1e3,
                 (now_s() - t4) * 1e3);
-    return BRX_OK;
-}
-
-int format_batch(const Batch &b, RawBuf &o)
-{
-    const uint32_t n = b.n();
-    const uint64_t out_total = n ? b.out_offsets[n] : 0;
-    // exact size first, then raw copies (a vector insert per 80-byte line costs more than the copy itself)
-    uint64_t need = b.defs.size() + 2ull * n + out_total;
-    for (uint32_t r = 0; r < n; r++) {
-        const uint64_t len = b.out_offsets[r + 1] - b.out_offsets[r];
-        need += (len + LINE_BASES - 1) / LINE_BASES;
-    }
-    if (!o.reserve(need)) {
-        set_error("out of host memory formatting a batch (%llu B)", (unsigned long long)need);
-        return BRX_ERR_NOMEM;
-    }
-    char *w = o.p;
-    uint32_t dprev = 0;
-    for (uint32_t r = 0; r < n; r++) {
-        *w++ = '>';
-        const uint32_t dl = b.def_end[r] - dprev;
-        memcpy(w, b.defs.data() + dprev, dl);
-        w += dl;
-        dprev = b.def_end[r];
-        *w++ = '\n';
-        const char *seq = (const char *)b.out.p + b.out_offsets[r];
-        uint64_t len = b.out_offsets[r + 1] - b.out_offsets[r];
-        while (len >= LINE_BASES) {
-            memcpy(w, seq, LINE_BASES);
-            w += LINE_BASES;
-            *w++ = '\n';
-            seq += LINE_BASES;
-            len -= LINE_BASES;
-        }
-        if (len) {
-            memcpy(w, seq, len);
-            w += len;
-            *w++ = '\n';
-        }
-    }
-    o.len = (size_t)(w - o.p);
     return BRX_OK;
 }
 
@@ -748,9 +821,7 @@ int brx_run_correction_fd(const brx_set_t *set, const brx_method_t *methods, uin
         while (q_ready.pop(b)) {
             if (!sh.failed()) {
                 const double t0 = now_s();
-                st = correct_one_batch(chain, dv, s, *b);
-                if (st == BRX_OK) // the 80-column text too: this thread would otherwise only wait for the next batch
-                    st = format_batch(*b, b->text);
+                st = correct_one_batch(chain, dv, s, *b); // (leaves the batch's FASTA text in b->text)
                 const double dt = now_s() - t0;
                 if (st != BRX_OK)
                     sh.fail(st);
@@ -781,45 +852,96 @@ int brx_run_correction_fd(const brx_set_t *set, const brx_method_t *methods, uin
     for (int i = 0; i < n_workers; i++)
         gpu_threads.emplace_back(gpu_worker);
 
-    std::thread writer([&] {
-        uint64_t next = 0;
+    // The writer: the batches in stream order from one thread.  With BRX_PIPE_WRITERS=2..4 a seekable regular file (not
+    // O_APPEND) gets them from that many threads with pwrite at the offset the batch has in the stream, which is known as
+    // soon as every batch before it has been formatted (its length is then on record), not written.  Off by default:
+    // buffered writes to one file serialise on its inode lock (tmpfs, 1 Gbp: two writers took 0.35 s of write time
+    // between them against 0.16 s for one, the job 0.27 s against 0.25), so it only pays on a file system without that.
+    const off_t base_off = lseek(out_fd, 0, SEEK_CUR);
+    struct stat st_out;
+    const int fl = fcntl(out_fd, F_GETFL);
+    const int n_writers_env = [] { // read per call
+        const char *e = getenv("BRX_PIPE_WRITERS");
+        const int v = e ? atoi(e) : 1;
+        return v < 1 ? 1 : (v > 4 ? 4 : v);
+    }();
+    const bool positional = n_writers_env > 1 && base_off >= 0 && fl >= 0 && !(fl & O_APPEND) && fstat(out_fd, &st_out) == 0 &&
+                            S_ISREG(st_out.st_mode);
+    const int n_writers = positional ? n_writers_env : 1;
+    // stream offsets: len_of[seq] is recorded when the batch arrives in `done`; [0, frontier_seq) have their offsets
+    std::vector<uint64_t> len_of, off_of;
+    std::vector<char> have_len;
+    uint64_t frontier_seq = 0, frontier_off = 0;
+    auto advance_frontier = [&]() { // done_mu held
+        for (auto *d : done) {
+            if (d->seq >= have_len.size()) {
+                have_len.resize(d->seq + 64, 0);
+                len_of.resize(d->seq + 64, 0);
+                off_of.resize(d->seq + 64, 0);
+            }
+            if (!have_len[d->seq]) {
+                have_len[d->seq] = 1;
+                len_of[d->seq] = d->text_len;
+            }
+        }
+        while (frontier_seq < have_len.size() && have_len[frontier_seq]) {
+            off_of[frontier_seq] = frontier_off;
+            frontier_off += len_of[frontier_seq];
+            frontier_seq++;
+        }
+    };
+    uint64_t next_in_order = 0; // (one writer, no offsets: the next batch of the stream)
+    auto writer_fn = [&]() {
         for (;;) {
             Batch *b = nullptr;
+            uint64_t off = 0;
             {
                 std::unique_lock<std::mutex> g(done_mu);
                 done_cv.wait(g, [&] {
+                    advance_frontier();
                     for (auto *d : done)
-                        if (d->seq == next)
+                        if (positional ? d->seq < frontier_seq : d->seq == next_in_order)
                             return true;
                     return gpu_finished;
                 });
                 for (size_t i = 0; i < done.size(); i++)
-                    if (done[i]->seq == next) {
+                    if (positional ? done[i]->seq < frontier_seq : done[i]->seq == next_in_order) {
                         b = done[i];
                         done.erase(done.begin() + (long)i);
                         break;
                     }
                 if (!b)
-                    return; // GPU side finished and nothing in order is left
+                    return; // GPU side finished and nothing writable is left
+                off = positional ? off_of[b->seq] : 0;
+                next_in_order++;
             }
-            next++;
-            if (!sh.failed()) {
-                const double t0 = now_s();
-                int st = write_all(out_fd, b->text.p, b->text.len);
-                t_write += now_s() - t0;
-                if (pipe_trace())
-                    fprintf(stderr, "[brx pipe] t=%.1f ms: batch %llu written (%.1f ms)\n", (now_s() - t_start) * 1e3,
-                            (unsigned long long)b->seq, (now_s() - t0) * 1e3);
-                if (st != BRX_OK)
-                    sh.fail(st);
-                n_records += b->n();
-                bases_in += b->total;
-                bases_out += b->n() ? b->out_offsets[b->n()] : 0;
-                n_batches++;
+            int st = BRX_OK;
+            const double t0 = now_s();
+            if (!sh.failed())
+                st = positional ? pwrite_all(out_fd, (const char *)b->text.p, b->text_len, (uint64_t)base_off + off)
+                                : write_all(out_fd, (const char *)b->text.p, b->text_len);
+            const double dt = now_s() - t0;
+            if (pipe_trace())
+                fprintf(stderr, "[brx pipe] t=%.1f ms: batch %llu written (%.1f ms)\n", (now_s() - t_start) * 1e3,
+                        (unsigned long long)b->seq, dt * 1e3);
+            if (st != BRX_OK)
+                sh.fail(st);
+            {
+                std::lock_guard<std::mutex> g(done_mu);
+                t_write += dt;
+                if (st == BRX_OK && !sh.failed()) {
+                    n_records += b->n();
+                    bases_in += b->total;
+                    bases_out += b->out_total;
+                    n_batches++;
+                }
             }
             q_free.push(b);
         }
-    });
+    };
+    std::vector<std::thread> writers;
+    for (int i = 0; i < n_writers; i++)
+        writers.emplace_back(writer_fn);
 
     reader.join();
     for (auto &t : gpu_threads)
@@ -829,8 +951,13 @@ int brx_run_correction_fd(const brx_set_t *set, const brx_method_t *methods, uin
         gpu_finished = true;
     }
     done_cv.notify_all();
-    writer.join();
+    for (auto &t : writers)
+        t.join();
     q_free.close();
+    if (positional && lseek(out_fd, base_off + (off_t)frontier_off, SEEK_SET) < 0 && sh.status == BRX_OK) {
+        set_error("lseek to the end of the output: %s", strerror(errno));
+        return BRX_ERR_ARG;
+    }
     if (stats8) {
         stats8[0] = n_records;
         stats8[1] = bases_in;

@@ -23,9 +23,13 @@ def _expected(text: bytes, om, two_side: bool) -> bytes:
     return out.getvalue()
 
 
+@pytest.mark.parametrize("writers", ["1", "3"])
 @pytest.mark.parametrize("batch_records", [0, 7, 64])
 @pytest.mark.parametrize("two_side", [False, True])
-def test_native_pipeline_fixture(tmp_path, golden_dir, solid_fixture_bytes, batch_records, two_side):
+def test_native_pipeline_fixture(tmp_path, golden_dir, solid_fixture_bytes, batch_records, two_side, writers, monkeypatch):
+    """writers = 3: BRX_PIPE_WRITERS, positional writes of the batches from three threads (regular file outputs only);
+    the file and the position the descriptor is left at must be the same as with the one in-order writer"""
+    monkeypatch.setenv("BRX_PIPE_WRITERS", writers)
     gs = br_amd.Pcon.from_pcon_solid(solid_fixture_bytes)
     os_ = O.Solid.from_bytes(solid_fixture_bytes)
     om = O.build_methods(os_, ["one", "graph"], 5, 7)
@@ -33,9 +37,13 @@ def test_native_pipeline_fixture(tmp_path, golden_dir, solid_fixture_bytes, batc
     src = os.path.join(golden_dir, "raw.fasta")
     dst = tmp_path / "corr.fasta"
     with open(src, "rb") as fi, open(dst, "wb") as fo:
+        fo.write(b"#head\n")  # the output starts where the descriptor stands ...
         st = run_correction([fi], [fo], methods, two_side, native=True, batch_records=batch_records)
+        fo.write(b"#tail\n")  # ... and the descriptor is left at the end of what was written
     want = _expected(open(src, "rb").read(), om, two_side)
-    assert dst.read_bytes() == want
+    got = dst.read_bytes()
+    assert got[:6] == b"#head\n" and got[-6:] == b"#tail\n"
+    assert got[6:-6] == want
     assert st["records"] == 206 and st["bases_in"] == 2519592
     if batch_records == 7:
         assert st["batches"] >= 206 // 7
