@@ -68,7 +68,10 @@ while time.time() < t_end:
            "BRX_INDEX_FWD": str(rng.choice(["", "1", "31"])), "BRX_REDO_MAX": str(rng.choice(["", "", "0"])),
            "BRX_MAXPATH": str(rng.choice(["", "", "3"])),
            "BRX_INDEX_MIN_K": "5", "BRX_FORCE_SPARSE": str(rng.choice(["0", "0", "1"])),
-           "BRX_LAZY_BITS": str(rng.choice(["1", "0"])), "BRX_INDEX_LOG_LINES": str(rng.choice(["0", "0", "5"]))}
+           "BRX_LAZY_BITS": str(rng.choice(["1", "0"])), "BRX_INDEX_LOG_LINES": str(rng.choice(["0", "0", "5"])),
+           # the LDS hash count of the partitioned finish: wrong guesses of the share of distinct keys and tiny tables
+           "BRX_HF_RATIO": str(rng.choice(["", "", "0.01", "1"])), "BRX_HF_LOG_T": str(rng.choice(["", "", "6", "8"])),
+           "BRX_HF_MIN_LT": str(rng.choice(["", "", "4"]))}
     for key, v in env.items():
         if v == "":
             os.environ.pop(key, None)
