@@ -306,10 +306,12 @@ def main():
     cpu = e2e = None
     if rank == 0 and world == 1:
         # free the bench's own HBM/host buffers are not needed any more; the legs below bring their own
-        if not args.no_cpu_baseline:
-            cpu = cpu_baseline(args, cfg, gs, k, n_reads)
+        # the file-to-file leg first: behind the CPU baseline (16 threads for ~20 s, an 8 GiB table allocated and freed) its
+        # host stages measured 3-8x slower on the same box (build 1.0 s instead of 0.16 s per Gbp)
         if not args.no_e2e and args.config == 1 and n_reads <= 200_000:
             e2e = e2e_fasta(args, d_bases, d_off, n_reads, total, k, a)
+        if not args.no_cpu_baseline:
+            cpu = cpu_baseline(args, cfg, gs, k, n_reads)
 
     if rank == 0:
         value = total_all * args.steps / elapsed / 1e9
