@@ -1559,10 +1559,13 @@ static int part_finish_impl(brx_counter *c, uint32_t abundance, hipStream_t s, b
     // Buckets that end in the LDS hash table (no bit vector to write) and would average more keys than one table pass
     // takes even at high coverage: cut them finer at level 2 instead (k = 19: digits 9, 9 in place of 9, 8 -- 2^18
     // buckets with 19 bits left; configs[3]'s share per GPU then has 24 000 keys per bucket, ~5 000 of them distinct)
-    static const bool wide_on = [] { const char *e = getenv("BRX_WIDE_L2"); return !(e && *e == '0'); }();
-    static const bool lazy_on = [] { const char *e = getenv("BRX_LAZY_BITS"); return !(e && *e == '0'); }();
-    st->use_wide = wide_on && !d_hist && dst && (dst->sparse || (index_wanted(c->k) && lazy_on)) && st->pl.nlev == 3 &&
-                   st->pl_wide.bits[1] != st->pl.bits[1] && total / st->pl.nchild[1] > 16384;
+    // (BRX_WIDE_L2 = the average bucket size from which on the wider digit is used, 0 = never, 1 = always; read per call:
+    // the fuzzers force it on small inputs)
+    const char *e_wide = getenv("BRX_WIDE_L2");
+    const uint64_t wide_from = e_wide && *e_wide ? strtoull(e_wide, nullptr, 10) : 16384ull;
+    const bool lazy_on = [] { const char *e = getenv("BRX_LAZY_BITS"); return !(e && *e == '0'); }(); // (per call too)
+    st->use_wide = wide_from != 0 && !d_hist && dst && (dst->sparse || (index_wanted(c->k) && lazy_on)) && st->pl.nlev == 3 &&
+                   st->pl_wide.bits[1] != st->pl.bits[1] && (wide_from == 1 || total / st->pl.nchild[1] > wide_from);
     const Plan &pl = st->use_wide ? st->pl_wide : st->pl;
     const uint32_t B1 = (uint32_t)pl.nchild[0];
 
@@ -1648,7 +1651,7 @@ static int part_finish_impl(brx_counter *c, uint32_t abundance, hipStream_t s, b
     const uint64_t *poff = l1off;
     // no slices to write (lazy / sparse): stop one level early and hash-count the coarser buckets, if they are small
     // enough for an LDS table (k = 19 at 1 Gbp: 131 072 buckets of ~7 600 keys with 20 bits left)
-    static const bool hf_on = [] { const char *e = getenv("BRX_HASH_FINAL"); return !(e && *e == '0'); }();
+    const bool hf_on = [] { const char *e = getenv("BRX_HASH_FINAL"); return !(e && *e == '0'); }(); // (per call: fuzzers)
     const int R_hf = pl.rem_in[pl.nlev - 1];
     const uint64_t nb_hf = pl.nlev >= 2 ? pl.nchild[pl.nlev - 2] : 0;
     // (up to 2^17 keys per bucket: the table then takes a bucket in a few passes over its key range, see hash_final_kernel)

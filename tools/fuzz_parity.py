@@ -71,7 +71,8 @@ while time.time() < t_end:
            "BRX_LAZY_BITS": str(rng.choice(["1", "0"])), "BRX_INDEX_LOG_LINES": str(rng.choice(["0", "0", "5"])),
            # the LDS hash count of the partitioned finish: wrong guesses of the share of distinct keys and tiny tables
            "BRX_HF_RATIO": str(rng.choice(["", "", "0.01", "1"])), "BRX_HF_LOG_T": str(rng.choice(["", "", "6", "8"])),
-           "BRX_HF_MIN_LT": str(rng.choice(["", "", "4"]))}
+           "BRX_HF_MIN_LT": str(rng.choice(["", "", "4"])), "BRX_WIDE_L2": str(rng.choice(["", "1", "0"])),
+           "BRX_HASH_FINAL": str(rng.choice(["", "", "0"]))}
     for key, v in env.items():
         if v == "":
             os.environ.pop(key, None)
