@@ -951,7 +951,9 @@ __global__ __launch_bounds__(BLOCK) void hash_final_kernel(const uint32_t *__res
         const uint64_t s0 = off[b], n = off[b + 1] - s0;
         if (n == 0)
             continue;
-        // passes: 2^lp disjoint ranges of the R-bit key, each expected to bring <= 5/8 T DISTINCT keys
+        // passes: 2^lp disjoint ranges of the R-bit key, each expected to bring <= 5/8 T DISTINCT keys (measured: 3/8 costs
+        // configs[3]'s share 39.9 -> 45.7 ms in extra passes, 7/8 costs configs[2] 83 -> 117 ms in overflowing tables; 4
+        // slots per key instead of 2.5 below: no difference, 1.5: +23 % -- profiles/r2_one_kernel_ab.txt)
         const uint64_t n_eff = (uint64_t)((float)n * ratio) + 1ull;
         uint32_t lp = 0;
         while (lp < (uint32_t)R && (n_eff >> lp) > (uint64_t)(Tmax / 8u * 5u))
