@@ -889,6 +889,10 @@ __global__ __launch_bounds__(64 * P3_WAVES) void final_count_kernel(const uint16
 // 2^lp passes over disjoint key ranges.  lp is chosen for the DISTINCT keys expected -- n x the ratio hf_sample_kernel
 // measured on a few buckets: at 20x coverage a bucket of 48 000 keys has ~10 000 different ones -- and a pass whose
 // keys still do not fit is repeated 4x finer.
+#ifndef BRX_HF_FLAT
+#define BRX_HF_FLAT 1
+#endif
+constexpr bool HF_FLAT = BRX_HF_FLAT != 0;
 constexpr uint32_t HF_VALID = 0x80000000u;
 constexpr int HF_CHUNK = 8;
 constexpr uint32_t HF_MAX_TRIES = 192; // probes before a key calls the table full (a cluster that long means it nearly is)
@@ -978,8 +982,39 @@ __global__ __launch_bounds__(BLOCK) void hash_final_kernel(const uint32_t *__res
 #pragma unroll
               for (int c = 0; c < HF_CHUNK; c++) {
                   const uint64_t i = i0 + (uint64_t)c * TEAM + tl;
-                  kbuf[c] = i < n ? keys[s0 + i] : 0xffffffffu;
+                  kbuf[c] = i < n ? keys[s0 + i] : 0xffffffffu; // (a clamped index instead of the branch: 3.39 -> 5.24 ms)
               }
+              if constexpr (HF_FLAT && TEAM > 64) {
+#pragma unroll
+              for (int c = 0; c < HF_CHUNK; c++) {
+                // One key per lane, flat: the loop runs while any lane of the wave is still probing, every turn is the same
+                // straight code -- read the slot, claim it if empty, count if it holds the key -- with the two atomics as its
+                // only predicated regions (the nested ifs and breaks of the obvious form cost ~30 scalar instructions per
+                // turn in exec-mask bookkeeping: the scalar unit, 68 % busy, was the kernel's busiest; profiles/r2j_sq_summary.json)
+                const uint32_t key = kbuf[c];
+                uint32_t pend = (key != 0xffffffffu && !(lp && (key >> ((uint32_t)R - lp)) != pass)) ? 1u : 0u;
+                uint32_t h = (key * 0x9E3779B1u) >> (32u - lt);
+                const uint32_t mine = HF_VALID | (key << 11);
+                for (uint32_t tries = 0; __any(pend); tries++) {
+                    const uint32_t e = tab[h]; // (lanes that are done read a slot they do not use)
+                    uint32_t r = e;
+                    if (pend & (uint32_t)(e == 0u))
+                        r = atomicCAS(&tab[h], 0u, mine | 1u);
+                    const uint32_t won = (uint32_t)(e == 0u) & (uint32_t)(r == 0u);
+                    const uint32_t same = (uint32_t)((r & 0xfffff800u) == mine);
+                    if (pend & same & (uint32_t)((r & 0x400u) == 0u)) // saturates far above 255 and far below the key bits
+                        atomicAdd(&tab[h], 1u);
+                    pend &= ~(won | same) & 1u;
+                    if (tries >= HF_MAX_TRIES) { // (uniform) the table is as good as full: this pass needs a finer split
+                        if (pend)
+                            ctl[1] = 1;
+                        pend = 0;
+                    }
+                    h = (h + 1u) & (T - 1u);
+                }
+              }
+              } else {
+              // (one wave per bucket: the form with breaks measured 7 % faster there -- 66.7 against 71.8 ms at configs[4]'s share)
 #pragma unroll
               for (int c = 0; c < HF_CHUNK; c++) {
                 const uint32_t key = kbuf[c];
@@ -1005,6 +1040,7 @@ __global__ __launch_bounds__(BLOCK) void hash_final_kernel(const uint32_t *__res
                     }
                     h = (h + 1u) & (T - 1u);
                 }
+              }
               }
             }
             team_sync();

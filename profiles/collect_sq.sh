@@ -27,7 +27,7 @@ for f in glob.glob(out + "/a/*kernel_trace.csv"):
         dur[name].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
 res = {}
 for name, c in agg.items():
-    if "correct_kernel" not in name and "one_kernel" not in name and "final_count" not in name and "scatter" not in name:
+    if not any(t in name for t in ("correct_kernel", "one_kernel", "final_count", "scatter", "hash_final", "_hist", "index_insert")):
         continue
     d = {k: sum(v) / len(v) for k, v in c.items()}
     d["ms"] = sum(dur[name]) / max(len(dur[name]), 1)
