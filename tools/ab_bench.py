@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=2)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--config", type=int, default=1)
+    ap.add_argument("--bench-args", default="", help="extra arguments for bench.py, e.g. '--method graph'")
     ap.add_argument("--env", action="append", default=[], help="TAG:KEY=VALUE sets an environment variable for the variants named LIB+TAG")
     args = ap.parse_args()
     extra = {}
@@ -36,7 +37,7 @@ def main():
             for tag in v.split("+")[1:]:  # "default+nowide" = the default library with the variables given as --env nowide:K=V
                 env.update(extra[tag])
             out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", str(args.steps), "--warmup", "2",
-                                  "--config", str(args.config), "--no-cpu-baseline", "--no-e2e"], env=env, capture_output=True, text=True)
+                                  "--config", str(args.config), "--no-cpu-baseline", "--no-e2e"] + args.bench_args.split(), env=env, capture_output=True, text=True)
             line = [l for l in out.stdout.splitlines() if l.startswith("{")]
             if not line:
                 print(v, "FAILED", out.stderr[-400:], flush=True)
