@@ -1320,6 +1320,28 @@ int part_begin(brx_counter *c)
         w.bits[2] -= moved;
         w.rem_in[2] -= moved;
         w.nchild[1] <<= moved;
+    } else if (pl.nlev == 4) {
+        // four levels (k = 21: 9/7/7/6, hash count on 2^23 buckets of 18 bits): a 9-bit second digit and just enough third
+        // digit to leave the 20 bits an LDS table entry can hold -- 9/9/3/8 -- ends in 2^21 buckets, four times as big:
+        // from ~640 keys per bucket on they are taken by 1024-lane workgroups (3.4-5 ms per G keys) instead of one wave
+        // each (6-11 ms per G keys, most of it per-bucket overhead on the scalar unit, profiles/r2j_sq_k21_summary.json)
+        Plan &w = st->pl_wide;
+        const int P = pl.bits[0] + pl.bits[1] + pl.bits[2] + pl.bits[3];
+        const int b1 = MAX_DIGIT_BITS;
+        int b2 = (pl.nbits - pl.bits[0] - b1) - 20;
+        if (b2 < 0)
+            b2 = 0;
+        const int b3 = P - pl.bits[0] - b1 - b2;
+        if (b3 >= 0 && b3 <= MAX_DIGIT_BITS && b2 <= MAX_DIGIT_BITS) {
+            w.bits[1] = b1;
+            w.bits[2] = b2;
+            w.bits[3] = b3;
+            w.rem_in[2] = w.rem_in[1] - b1;
+            w.rem_in[3] = w.rem_in[2] - b2;
+            w.nchild[1] = w.nchild[0] << b1;
+            w.nchild[2] = w.nchild[1] << b2;
+            w.nchild[3] = w.nchild[2] << b3;
+        }
     }
     hipError_t e = hipMalloc((void **)&st->d_scalars, 32);
     for (int l = 0; l < pl.nlev && e == hipSuccess; l++) {
@@ -1602,8 +1624,11 @@ static int part_finish_impl(brx_counter *c, uint32_t abundance, hipStream_t s, b
     const char *e_wide = getenv("BRX_WIDE_L2");
     const uint64_t wide_from = e_wide && *e_wide ? strtoull(e_wide, nullptr, 10) : 16384ull;
     const bool lazy_on = [] { const char *e = getenv("BRX_LAZY_BITS"); return !(e && *e == '0'); }(); // (per call too)
-    st->use_wide = wide_from != 0 && !d_hist && dst && (dst->sparse || (index_wanted(c->k) && lazy_on)) && st->pl.nlev == 3 &&
-                   st->pl_wide.bits[1] != st->pl.bits[1] && (wide_from == 1 || total / st->pl.nchild[1] > wide_from);
+    st->use_wide = wide_from != 0 && !d_hist && dst && (dst->sparse || (index_wanted(c->k) && lazy_on)) &&
+                   st->pl_wide.bits[1] != st->pl.bits[1] &&
+                   (wide_from == 1 || (st->pl.nlev == 3 ? total / st->pl.nchild[1] > wide_from
+                                                        // four levels: as soon as the wider buckets fill a workgroup
+                                                        : total / st->pl_wide.nchild[2] > 640));
     const Plan &pl = st->use_wide ? st->pl_wide : st->pl;
     const uint32_t B1 = (uint32_t)pl.nchild[0];
 
