@@ -884,11 +884,13 @@ __global__ __launch_bounds__(64 * P3_WAVES) void final_count_kernel(const uint16
 // When the set is only listed (lazy bit vector / sparse set) nothing forces the last radix level: a bucket of
 // 2^R hashes (R <= 20 bits left in the keys) with a few thousand keys is counted directly in an LDS hash table
 // (open addressing, entry = valid | key << 11 | count), and the entries with count > abundance are listed.  That
-// replaces the last level's histogram + scatter and the per-4096-hash counting pass.  A TEAM of 256 (one
-// workgroup) or 64 lanes (one wave) takes a bucket; a bucket with more keys than the table can take is done in
+// replaces the last level's histogram + scatter and the per-4096-hash counting pass.  A TEAM of 1024 lanes (one
+// workgroup; buckets of 640 keys and more on average) or 64 lanes (one wave) takes a bucket; a bucket with more keys than the table can take is done in
 // 2^lp passes over disjoint key ranges.  lp is chosen for the DISTINCT keys expected -- n x the ratio hf_sample_kernel
 // measured on a few buckets: at 20x coverage a bucket of 48 000 keys has ~10 000 different ones -- and a pass whose
-// keys still do not fit is repeated 4x finer.
+// keys still do not fit is repeated with the whole table, then 4x finer.  Each bucket's table has 2.5 slots per distinct key
+// expected, not the launch's maximum.  What binds the kernel and what was tried: DESIGN.md section 4,
+// profiles/r2_one_kernel_ab.txt.
 #ifndef BRX_HF_FLAT
 #define BRX_HF_FLAT 1
 #endif
@@ -977,7 +979,7 @@ __global__ __launch_bounds__(BLOCK) void hash_final_kernel(const uint32_t *__res
                 *(uint4 *)(tab + q) = make_uint4(0u, 0u, 0u, 0u);
             team_sync();
             for (uint64_t i0 = 0; i0 < n; i0 += (uint64_t)TEAM * HF_CHUNK) {
-              // HF_CHUNK independent loads in flight per thread, then the (LDS-latency-bound) inserts
+              // HF_CHUNK independent loads in flight per thread, then the inserts
               uint32_t kbuf[HF_CHUNK];
 #pragma unroll
               for (int c = 0; c < HF_CHUNK; c++) {
