@@ -12,6 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("BRX_LIB_PATH") or os.path.join(_HERE, "lib", "libbrx.so")  # override: A/B of builds
 
 BRX_OK = 0
+BRX_ERR_ARG = -1
 BRX_ERR_OVERFLOW = -7
 BRX_ERR_NODEVICE = -4
 BRX_ERR_UNSUPPORTED = -6
@@ -89,6 +90,7 @@ SIGNATURES = {
     "brx_comm_info": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "brx_exchange_build_partitioned": (C.c_int, [_vp, _vp, C.c_uint8, _vp, _vp]),
     "brx_exchange_reduce_counts": (C.c_int, [_vp, _vp, C.c_uint8, _vp]),
+    "brx_exchange_plan": (C.c_int, [_u64p, C.c_int, C.c_uint32, C.c_int, C.POINTER(C.c_uint32), _u64p, _u64p, _u64p, _u64p]),
     "brx_comm_last_stats": (C.c_int, [_vp, _u64p]),
     "brx_comm_free": (None, [_vp]),
     "brx_chain_new": (C.c_int, [_vp, C.POINTER(Method), C.c_uint32, C.c_bool, _pp]),

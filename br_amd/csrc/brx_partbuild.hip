@@ -1403,6 +1403,12 @@ int part_l1_view(brx_counter *c, void **d_keys, void **d_l1off, uint32_t *n_buck
 {
     PartState *st = c->part;
     *n_buckets = (uint32_t)st->pl.nchild[0];
+    if (st->batches.empty()) { // nothing counted (an empty shard): no keys, and the caller takes every offset as 0
+        *d_keys = nullptr;
+        *d_l1off = nullptr;
+        *n_keys = 0;
+        return BRX_OK;
+    }
     if (st->batches.size() != 1 || st->batches[0].borrowed) {
         set_error("l1_view needs exactly one locally counted batch (have %zu)", st->batches.size());
         return BRX_ERR_ARG;

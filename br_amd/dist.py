@@ -134,20 +134,34 @@ class AbiExchange:
     the hand-over of the 128-byte communicator id from rank 0 to the other ranks, through the process group the
     host already has (any out-of-band channel would do)."""
 
-    def __init__(self, world: int, rank: int, device: int):
+    def __init__(self, world: int, rank: int, device: int, ident: Optional[bytes] = None):
+        """`ident`: the 128 bytes of `unique_id()` as rank 0 made them, when the host has its own channel for them
+        (a file, a socket); without it they travel through the torch.distributed process group."""
         import ctypes as C
         from . import _lib
         self.world, self.rank, self.device = world, rank, device
         L = _lib.lib()
-        ident = (C.c_uint8 * 128)()
-        if rank == 0:
-            _lib.check(L.brx_comm_unique_id(ident))
-        if world > 1:
-            box = [bytes(ident)]
-            dist.broadcast_object_list(box, src=0)
-            ident = (C.c_uint8 * 128).from_buffer_copy(box[0])
+        if ident is not None:
+            ident = (C.c_uint8 * 128).from_buffer_copy(ident)
+        else:
+            ident = (C.c_uint8 * 128)()
+            if rank == 0:
+                _lib.check(L.brx_comm_unique_id(ident))
+            if world > 1:
+                box = [bytes(ident)]
+                dist.broadcast_object_list(box, src=0)
+                ident = (C.c_uint8 * 128).from_buffer_copy(box[0])
         self._h = C.c_void_p()
         _lib.check(L.brx_comm_init(ident, world, rank, device, C.byref(self._h)))
+
+    @staticmethod
+    def unique_id() -> bytes:
+        """brx_comm_unique_id: rank 0 makes it, every rank passes the same bytes to the constructor"""
+        import ctypes as C
+        from . import _lib
+        ident = (C.c_uint8 * 128)()
+        _lib.check(_lib.lib().brx_comm_unique_id(ident))
+        return bytes(ident)
 
     def build_partitioned(self, counter, solid, abundance: int, stream: Optional[int] = None) -> None:
         from . import _lib

@@ -212,6 +212,15 @@ int brx_exchange_build_partitioned(brx_comm_t *comm, brx_counter_t *c, uint8_t a
  * abundance` (counts are clamped to abundance+1 first; int32 slices once world*(abundance+1) > 255); the caller
  * then runs brx_set_count_finish[_into] on every rank.                                                          */
 int brx_exchange_reduce_counts(brx_comm_t *comm, brx_counter_t *c, uint8_t abundance, void *stream);
+/* The host-side arithmetic of brx_exchange_build_partitioned, a pure function (no GPU, no communicator): from the
+ * `world` level-1 offset tables (each n_buckets+1 entries, non-decreasing from 0) it gives, for `rank`, the owner
+ * bounds (world+1: rank r owns first digits [bound[r], bound[r+1]) = [r*n_buckets/world, ...)), the keys it sends to
+ * and receives from every rank, optionally the per-source segment tables (world x (n_buckets+1): the source's table
+ * clamped to the owned range and rebased to the received segment) and the largest single message of the job (what
+ * fixes the number of capped rounds on every rank alike).  Exposed so that hosts and tests can check the layout for
+ * any world size; there is no reference counterpart (one process, src/main.rs:30-33).                            */
+int brx_exchange_plan(const uint64_t *tables, int world, uint32_t n_buckets, int rank, uint32_t *bound, uint64_t *send_counts,
+                      uint64_t *recv_counts, uint64_t *seg /* may be NULL */, uint64_t *largest_message /* may be NULL */);
 /* last build_partitioned: [0] key bytes sent, [1] received, [2] keys counted by this owner, [3] its solid k-mers,
  * [4] solid k-mers of the job, [5] all-to-all us, [6] whole call us, [7] largest single message (keys)          */
 int brx_comm_last_stats(const brx_comm_t *comm, uint64_t *stats8);

@@ -182,3 +182,83 @@ def test_cli_rejects_values_outside_u8():
             cli.parser().parse_args(argv)
     with pytest.raises(ValueError):
         br_amd.set._check_u8(300, "abundance")
+
+
+# ---------------------------------------------------------------- multi-GPU exchange: host arithmetic ----------
+def _plan(tables, world, nb, rank):
+    import ctypes as C
+    L = _lib.lib()
+    T = nb + 1
+    tab = np.ascontiguousarray(np.asarray(tables, dtype=np.uint64).reshape(world * T))
+    bound = np.zeros(world + 1, np.uint32)
+    sc, rc = np.zeros(world, np.uint64), np.zeros(world, np.uint64)
+    seg = np.zeros(world * T, np.uint64)
+    big = C.c_uint64(0)
+    u64p, u32p = C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)
+    st = L.brx_exchange_plan(tab.ctypes.data_as(u64p), world, nb, rank, bound.ctypes.data_as(u32p), sc.ctypes.data_as(u64p),
+                             rc.ctypes.data_as(u64p), seg.ctypes.data_as(u64p), C.byref(big))
+    return st, bound, sc, rc, seg.reshape(world, T), int(big.value)
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 5, 8])
+@pytest.mark.parametrize("nb", [4, 13, 512])
+def test_exchange_plan_layout(world, nb):
+    """brx_exchange_plan, the pure host arithmetic of brx_exchange_build_partitioned (owner bounds, per-peer counts,
+    clamped + rebased segment tables, the job's largest message), against a direct numpy statement on synthetic
+    level-1 offset tables -- including empty ranks and ranks whose keys all sit in one digit."""
+    if nb < world:
+        pytest.skip("fewer buckets than ranks is covered by test_exchange_plan_more_ranks_than_buckets")
+    rng = np.random.default_rng(world * 1000 + nb)
+    counts = rng.integers(0, 50, size=(world, nb)).astype(np.uint64)
+    if world > 1:
+        counts[1] = 0                                           # a rank that counted nothing
+    if world > 2:
+        counts[2] = 0
+        counts[2, nb - 1] = 12345                               # everything in the last digit
+    tables = np.concatenate([np.zeros((world, 1), np.uint64), np.cumsum(counts, axis=1)], axis=1)
+    exp_bound = [r * nb // world for r in range(world + 1)]
+    sent_total = np.zeros((world, world), np.uint64)
+    for me in range(world):
+        st, bound, sc, rc, seg, big = _plan(tables, world, nb, me)
+        assert st == 0 and bound.tolist() == exp_bound
+        for r in range(world):
+            assert sc[r] == counts[me, exp_bound[r]:exp_bound[r + 1]].sum()
+            assert rc[r] == counts[r, exp_bound[me]:exp_bound[me + 1]].sum()
+            # the segment table of source r: inside the owned range the running count of the received keys, flat outside
+            lo, hi = exp_bound[me], exp_bound[me + 1]
+            e = np.zeros(nb + 1, np.uint64)
+            e[lo:hi + 1] = np.concatenate([[0], np.cumsum(counts[r, lo:hi])])
+            e[hi + 1:] = e[hi]
+            assert np.array_equal(seg[r], e)
+        sent_total[me] = sc
+        assert big == max(counts[x, exp_bound[y]:exp_bound[y + 1]].sum() for x in range(world) for y in range(world))
+    # what rank x sends to y is what y expects from x, and nothing is lost
+    for me in range(world):
+        _, _, _, rc, _, _ = _plan(tables, world, nb, me)
+        assert np.array_equal(rc, sent_total[:, me])
+    assert sent_total.sum() == counts.sum()
+
+
+def test_exchange_plan_more_ranks_than_buckets():
+    """4 first digits over 8 ranks: half of the ranks own an empty digit range and receive nothing"""
+    world, nb = 8, 4
+    counts = np.arange(1, world * nb + 1, dtype=np.uint64).reshape(world, nb)
+    tables = np.concatenate([np.zeros((world, 1), np.uint64), np.cumsum(counts, axis=1)], axis=1)
+    owners = 0
+    for me in range(world):
+        st, bound, sc, rc, seg, _ = _plan(tables, world, nb, me)
+        assert st == 0
+        if bound[me] == bound[me + 1]:
+            assert rc.sum() == 0 and seg.sum() == 0
+        else:
+            owners += 1
+            assert rc.sum() == counts[:, bound[me]:bound[me + 1]].sum()
+        assert sc.sum() == counts[me].sum()
+    assert owners == nb
+
+
+def test_exchange_plan_rejects_bad_tables():
+    st = _plan([[0, 3, 2]], 1, 2, 0)[0]            # decreasing
+    assert st == _lib.BRX_ERR_ARG
+    st = _plan([[1, 3, 4]], 1, 2, 0)[0]            # does not start at 0
+    assert st == _lib.BRX_ERR_ARG

@@ -165,3 +165,76 @@ def test_config4_share_k21_graph_gap_size():
         assert got == O.correct_record(om, src, False), r
         changed += got != src
     assert changed > len(sample) // 2
+
+
+def test_config3_share_k19_one():
+    """BASELINE configs[3]'s per-GPU share: 625 000 reads (6.25 Gbp of a 125 Mbp genome), k = 19, set build THROUGH THE
+    SHIPPED EXCHANGE (brx_exchange_build_partitioned, real librccl, world 1) + correct::one forward and reverse.  This
+    size takes paths configs[1] never reaches: the 9-bit second digit, hash-count passes over key ranges, ~130 M solid
+    k-mers -> 16-mer minimizers and more than 2^25 index lines under `one_kernel`."""
+    import torch
+    K, N = 19, 625_000
+    cfg, db, do, total, stream = _make_reads(N)
+    cnt = br_amd.Counter(K, 0, _lib.COUNT_SORTED)
+    cnt.add_batch_device(db.data_ptr(), do.data_ptr(), N, total, stream)
+    solid = br_amd.Pcon.new(K, 0)
+    ex = bd.AbiExchange(1, 0, 0)
+    ex.build_partitioned(cnt, solid, ABUNDANCE, stream)
+    st = ex.last_stats()
+    ex.close()
+    n_solid = solid.popcount()
+    assert st["solid_job"] == n_solid and st["keys_counted_here"] > 6_000_000_000
+    assert 0.95 * cfg.genome_len < n_solid < 1.25 * cfg.genome_len
+    info = solid.index_info()
+    assert info["valid"] and info["m"] == 16 and info["log2_lines"] > 25
+
+    off_h = do.cpu().numpy()
+    chain = br_amd.Chain(solid, [("one", 5, 7)], two_side=False)
+    out, oo, tot = _correct(chain, db, do, N, total, stream)
+    cst = chain.last_stats()
+    assert cst["fixes"] > 20_000_000
+    oo_h = oo.cpu().numpy()
+    assert int(oo_h[-1]) == tot
+
+    # the plain finish of the same counter contents, and the reference's own structure (128 GiB of u8 counters): same set
+    cnt.add_batch_device(db.data_ptr(), do.data_ptr(), N, total, stream)
+    plain = cnt.finish(ABUNDANCE, stream)
+    del cnt
+    assert plain.popcount() == n_solid
+    pa, na = solid.device_bits()
+    pb, nb_ = plain.device_bits()
+    assert na == nb_ and torch.equal(bd.device_view(pa, na).view(torch.int64), bd.device_view(pb, nb_).view(torch.int64))
+    del plain
+    cnt = br_amd.Counter(K, 0, _lib.COUNT_DENSE)
+    cnt.add_batch_device(db.data_ptr(), do.data_ptr(), N, total, stream)
+    dense = cnt.finish(ABUNDANCE, stream)
+    del cnt
+    torch.cuda.synchronize()
+    pb, nb_ = dense.device_bits()
+    assert torch.equal(bd.device_view(pa, na).view(torch.int64), bd.device_view(pb, nb_).view(torch.int64))
+    del dense
+
+    # batch-split invariance: the last 225 000 reads on their own give the same bytes
+    a = 400_000
+    nb2 = int(off_h[N] - off_h[a])
+    sub_off = (do[a:] - do[a]).contiguous()
+    out2 = torch.empty(int(nb2 * 1.06) + (1 << 20), dtype=torch.uint8, device="cuda")
+    oo2 = torch.empty(N - a + 1, dtype=torch.int64, device="cuda")
+    tot2 = chain.correct_batch_device(db.data_ptr() + int(off_h[a]), sub_off.data_ptr(), N - a, nb2, out2.data_ptr(), out2.numel(),
+                                      oo2.data_ptr(), stream)
+    assert tot2 == tot - int(oo_h[a])
+    assert torch.equal(out2[:tot2], out[int(oo_h[a]):tot])
+    del out2, oo2
+
+    # 64 reads against the oracle with the very set the GPU built (16 GiB exported from HBM)
+    bits = solid.export_bits()
+    om = O.build_methods(O.Solid.wrap(K, bits), ["one"], 5, 7)
+    rng = np.random.default_rng(11)
+    sample = sorted(set(rng.integers(0, N, size=62).tolist()) | {0, N - 1})
+    changed = 0
+    for r in sample:
+        src = db[int(off_h[r]):int(off_h[r + 1])].cpu().numpy().tobytes()
+        got = out[int(oo_h[r]):int(oo_h[r + 1])].cpu().numpy().tobytes()
+        assert got == O.correct_record(om, src, False), r
+        changed += got != src
+    assert changed > len(sample) // 2
