@@ -92,6 +92,27 @@ __device__ __forceinline__ uint32_t pack4(uint32_t w)
 #ifndef BRX_XCD_ITEMS
 #define BRX_XCD_ITEMS 1
 #endif
+// -DBRX_DEBUG_BOUNDS=1 (tools/ab_build.sh): every scatter store of the partition passes is checked against the size of
+// its destination; an index outside it is counted in bounds_violations (brx_debug_bounds_violations()) and the store
+// is dropped.  For builds that leave phases out to time the rest ("results wrong, time only"): such a build has
+// undefined offsets, and on a shared pool an undefined offset must not become a wild store (profiles/r2j_ab_runs.txt,
+// ab13).  The shipped build compiles none of it.
+#ifndef BRX_DEBUG_BOUNDS
+#define BRX_DEBUG_BOUNDS 0
+#endif
+#if BRX_DEBUG_BOUNDS
+__device__ unsigned long long bounds_violations = 0ull;
+__device__ __forceinline__ bool store_ok(uint64_t idx, uint64_t cap)
+{
+    if (idx >= cap) {
+        atomicAdd(&bounds_violations, 1ull);
+        return false;
+    }
+    return true;
+}
+#else
+__device__ __forceinline__ bool store_ok(uint64_t, uint64_t) { return true; }
+#endif
 constexpr bool XCD_ITEMS = BRX_XCD_ITEMS != 0;
 constexpr uint32_t L1_TILE = 4096;                    // k-mer start positions per level-1 work item (8192: scatter 5.4 ms, 4096: 4.3, 2048: 5.9 at 1 Gbp -- 35 KB of LDS = 4 blocks per CU)
 constexpr uint32_t PACK_WORDS = L1_TILE / 16 + 4;     // bases of the tile + k - 1 + slack, 16 per word
@@ -166,6 +187,7 @@ struct L1Args {
     uint32_t *matrix;        // [n_items][B] per-tile digit counts (hist): a tile's B counters are one coalesced row ...
     const uint64_t *pos;     // ... and, same layout, where the tile's keys of each digit go (col_scan_* below)
     uint32_t *keys_out;      // hash with the digit stripped
+    uint64_t out_cap;        // entries of keys_out (checked under BRX_DEBUG_BOUNDS)
 };
 
 __device__ __forceinline__ void l1_prepare(const L1Args &a, uint32_t item, uint32_t *pk, uint32_t *bnd, uint32_t *sh_r0,
@@ -477,7 +499,9 @@ __global__ __launch_bounds__(256) void l1_scatter_kernel(L1Args a)
         const uint32_t n_tile = lofs[B - 1] + cntv[B - 1];
         for (uint32_t idx = threadIdx.x; idx < n_tile; idx += 256) {
             const uint32_t d = stage_dig[idx];
-            a.keys_out[gbase[d] + (idx - lofs[d])] = stage_key[idx];
+            const uint64_t at = gbase[d] + (idx - lofs[d]);
+            if (store_ok(at, a.out_cap))
+                a.keys_out[at] = stage_key[idx];
         }
         __syncthreads();
     }
@@ -518,6 +542,7 @@ struct LnArgs {
     uint32_t *matrix;            // [parent][B][tiles of the parent] digit counts, index B*item_off[p] + b*ntiles_p + t
     const uint64_t *pos;         // exclusive scan of matrix
     void *keys_out;
+    uint64_t in_cap, out_cap;    // entries of keys_in / keys_out (checked under BRX_DEBUG_BOUNDS)
 };
 
 template <int KPT>
@@ -530,7 +555,7 @@ __device__ __forceinline__ uint32_t ln_load(const LnArgs &a, uint64_t parent, ui
 #pragma unroll
     for (int q = 0; q < KPT; q++) {
         const uint64_t i = lo + (uint64_t)q * 256 + threadIdx.x;
-        if (i < hi) {
+        if (i < hi && store_ok(i, a.in_cap)) {
             key[q] = a.keys_in[i];
             cnt = q + 1;
         }
@@ -663,7 +688,9 @@ __global__ __launch_bounds__(256) void ln_scatter_kernel(LnArgs a)
         const uint32_t n_tile = lofs[B - 1] + cntv[B - 1];
         for (uint32_t idx = threadIdx.x; idx < n_tile; idx += 256) {
             const uint32_t d = stage_dig[idx];
-            out[gbase[d] + (idx - lofs[d])] = (OUT)stage_key[idx];
+            const uint64_t at = gbase[d] + (idx - lofs[d]);
+            if (store_ok(at, a.out_cap))
+                out[at] = (OUT)stage_key[idx];
         }
         __syncthreads();
     }
@@ -1500,6 +1527,7 @@ int part_add_batch(brx_counter *c, const uint8_t *d_bases, const uint64_t *d_off
     a.matrix = st->d_matrix;
     a.pos = st->d_pos;
     a.keys_out = b.d_keys;
+    a.out_cap = b.cap;
     const int grid = n_items < 2048u ? (int)n_items : 2048;
     {
         KernelTimer t("part_l1_hist", s);
@@ -1578,6 +1606,7 @@ static int run_level(PartState *st, int l, const uint32_t *keys_in, const uint64
     LnArgs a;
     memset(&a, 0, sizeof(a));
     a.keys_in = keys_in;
+    a.in_cap = total;
     a.poff = poff;
     a.n_parents = n_parents;
     a.item_off = st->d_item_off;
@@ -1589,6 +1618,7 @@ static int run_level(PartState *st, int l, const uint32_t *keys_in, const uint64
     a.matrix = st->d_matrix;
     a.pos = st->d_pos;
     a.keys_out = keys_out;
+    a.out_cap = total + 64;
     const int grid = 256 * 8;
     {
         KernelTimer t(tag_hist, s);
@@ -1822,7 +1852,17 @@ static int part_finish_impl(brx_counter *c, uint32_t abundance, hipStream_t s, b
 
 int part_finish_into(brx_counter *c, uint32_t abundance, hipStream_t s, brx_set *dst)
 {
-    return part_finish_impl(c, abundance, s, dst, nullptr);
+    const int rc = part_finish_impl(c, abundance, s, dst, nullptr);
+#if BRX_DEBUG_BOUNDS
+    unsigned long long bad = 0;
+    BRX_HIP(hipStreamSynchronize(s));
+    BRX_HIP(hipMemcpyFromSymbol(&bad, HIP_SYMBOL(bounds_violations), 8));
+    if (bad) {
+        set_error("BRX_DEBUG_BOUNDS: %llu scatter stores / key loads of the partition passes were out of range and dropped", bad);
+        return BRX_ERR_HIP;
+    }
+#endif
+    return rc;
 }
 
 // bins 1..255 of the count spectrum into d_hist (256 x u64, zeroed by the caller); the counter is left as it was

@@ -554,6 +554,28 @@ def test_cli_reference_integration_commands(tmp_path, golden_dir, raw_reads, sol
         assert seq == O.correct_record(om, r, False)
 
 
+def test_config0_raw_fasta_k13_one(tmp_path, golden_dir, raw_reads):
+    """BASELINE configs[0] as a whole: `br -i raw.fasta -o corr.fasta -c one fasta -i raw.fasta -k 13 -a 2` through the
+    CLI path (count -> threshold -> correct::one forward + reverse -> 80-column FASTA), every one of the 206 records byte
+    for byte against the oracle (src/main.rs:72-115, src/lib.rs:22-69); and `-k 14` is forced odd like the reference's
+    Fasta::kmer_size (src/cli.rs:277-279), so it gives the same file."""
+    from br_amd import cli, fasta
+    raw = os.path.join(golden_dir, "raw.fasta")
+    out, out14 = str(tmp_path / "corr.fasta"), str(tmp_path / "corr14.fasta")
+    assert cli.main(["-i", raw, "-o", out, "-c", "one", "fasta", "-i", raw, "-k", "13", "-a", "2"]) == 0
+    ref = O.Solid.from_count(13, O.count_reads(13, raw_reads), 2)
+    om = O.build_methods(ref, ["one"], 5, 7)
+    got = list(fasta.read_records(open(out, "rb")))
+    assert len(got) == len(raw_reads) == 206
+    changed = 0
+    for (_, _, seq), r in zip(got, raw_reads):
+        assert seq == O.correct_record(om, r, False)
+        changed += seq != r
+    assert changed > 150
+    assert cli.main(["-i", raw, "-o", out14, "-c", "one", "fasta", "-i", raw, "-k", "14", "-a", "2"]) == 0
+    assert open(out14, "rb").read() == open(out, "rb").read()
+
+
 @pytest.mark.parametrize("strategy", [_lib.COUNT_DENSE, _lib.COUNT_SORTED])
 def test_spectrum_matches_oracle(raw_reads, strategy):
     cnt = br_amd.Counter(11, 0, strategy)
