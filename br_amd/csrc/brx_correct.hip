@@ -22,8 +22,7 @@
 // issued differs (probes are pure).  Output goes to a per-read slot of a staging buffer
 // (capacity = input length * (1 + slack/4) + 64); the reverse pass reads its input back to
 // front instead of materialising a reversed copy (src/lib.rs:111 reverses, does not complement).
-#include "brx_internal.hpp"
-#include "brx_index.hpp"
+#include "brx_correct.hpp"
 
 #include <stdlib.h>
 #include <string.h>
@@ -42,47 +41,6 @@ int upload_batch(const uint8_t *bases, const uint64_t *offsets, uint32_t n_reads
 }
 
 namespace {
-
-// control block layout (u64 words)
-enum { CTL_WORK = 0, CTL_OVERFLOW = 1, CTL_ROUNDS = 2, CTL_PROBES = 3, CTL_TRIGGERS = 4, CTL_FIXES = 5, CTL_TOTAL = 6, CTL_PATHOVF = 7, CTL_NONTERM = 8, CTL_N = 16 };
-
-struct PassParams {
-    const uint32_t *bits;
-    IdxView idx;      // lines == nullptr: every probe goes to the bitset
-    int k;
-    int c;            // confirm
-    uint32_t n_reads;
-    const uint64_t *offsets; // original batch offsets (n_reads+1), relative to batch start
-    // input view
-    const uint8_t *in;       // original bases or staging buffer
-    const uint32_t *in_lens; // nullptr => lengths from offsets (original batch)
-    int in_staged;           // 0: read r starts at offsets[r]; 1: at slot(r)
-    int flip;                // read the input back to front
-    // output view (always staged)
-    uint8_t *out;
-    uint32_t *out_lens;
-    uint32_t slack;          // slot(r) = o + (o>>2)*slack + 64*r
-    unsigned long long *ctrl;
-    // graph walks (Graph, GapSize): per-group list of visited k-mers, maxpath entries each
-    uint64_t *path_k;
-    uint32_t maxpath;
-    // greedy (greedy.rs): max_search and the per-group LDS carve-up for the alignment
-    uint32_t flags;       // tuning switches for A/B runs (BRX_TUNE): 1 no look-ahead reuse, 2 four ALTS probes, 4 unstaged SCEN
-    int max_search;
-    uint32_t g_dim;       // max (m+1), (n+1) of the DP = k + max_search + 2
-    uint32_t g_lds_bytes; // bytes of dynamic LDS per group
-};
-
-__host__ __device__ __forceinline__ uint64_t slot_of(uint64_t o, uint64_t r, uint32_t slack)
-{
-    return o + (o >> 2) * (uint64_t)slack + 64ull * r;
-}
-
-__device__ __forceinline__ bool probe(const uint32_t *__restrict__ bits, uint64_t fwd, int k)
-{
-    const uint64_t h = khash(fwd, k);
-    return (bits[h >> 5] >> (h & 31u)) & 1u;
-}
 
 enum { ST_INIT = 0, ST_SCAN, ST_ERRLEN, ST_ALTS, ST_SCEN, ST_MORE, ST_WALK, ST_T1, ST_TSCORE, ST_TMORE, ST_GFOLLOW, ST_GVALID };
 enum { MODE_ONE = 0, MODE_GRAPH = 1, MODE_INSSUB = 2, MODE_TWO = 3 };
@@ -355,36 +313,6 @@ __device__ __forceinline__ uint32_t scen_width(uint32_t sub, uint32_t c, int G, 
     const uint32_t share = alive <= 1u ? (uint32_t)G : (alive == 2u ? (uint32_t)G / 2u : (uint32_t)G / 3u);
     const uint32_t cap = (sub == 0u && !(flags & 4u)) ? (share < 2u ? share : 2u) : share;
     return left < cap ? left : cap;
-}
-
-template <int D>
-__device__ __forceinline__ uint32_t dpp_row_shr(uint32_t v)
-{
-    // lane l of a 16-lane row reads lane l - D of the same row; lanes without such a source read 0
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x110 + D, 0xf, 0xf, true);
-}
-
-// codes of the row's lanes first..this one, this lane's code in bits 0-1, the lane before in bits 2-3, ...
-__device__ __forceinline__ uint32_t row_scan16(uint32_t code)
-{
-    uint32_t v = code;
-    v |= dpp_row_shr<1>(v) << 2;
-    v |= dpp_row_shr<2>(v) << 4;
-    v |= dpp_row_shr<4>(v) << 8;
-    v |= dpp_row_shr<8>(v) << 16;
-    return v;
-}
-// this lane's k-mer in a 64-lane group: `carry` extended by the codes of lanes 0..lane (own row by the DPP scan, the two
-// rows before by row_bcast:15; rows 0 / 1 take those words from `carry`)
-__device__ __forceinline__ uint64_t lane_kmer64_dpp(uint64_t carry, uint32_t code, int lane, uint64_t mask)
-{
-    const uint32_t v = row_scan16(code);
-    const uint32_t clo = (uint32_t)carry, chi = (uint32_t)(carry >> 32);
-    const uint32_t b1 = (uint32_t)__builtin_amdgcn_update_dpp((int)clo, (int)v, 0x142 /* row_bcast:15 */, 0xe, 0xf, false);
-    const uint32_t old2 = (lane < 16) ? chi : clo;
-    const uint32_t b2 = (uint32_t)__builtin_amdgcn_update_dpp((int)old2, (int)b1, 0x142, 0xc, 0xf, false);
-    const uint32_t jb = 2u * ((uint32_t)(lane & 15) + 1u);
-    return (((((uint64_t)b2 << 32) | b1) << jb) | v) & mask; // jb <= 32
 }
 
 template <int G, int M>
@@ -1295,7 +1223,7 @@ __device__ __forceinline__ uint32_t row_scan8(uint32_t code)
     return v; // lanes 8..15 of a row also carry codes of lanes 0..7: the caller keeps 2 * (gl + 1) bits
 }
 
-template <int G, int KT>
+template <int G, int KT, bool LIST = false>
 __global__ __launch_bounds__(256, 7) void one_kernel(PassParams p)
 {
     static_assert(G == 4 || G == 8 || G == 16 || G == 64, "one_kernel: 4, 8, 16 or 64 lanes per read");
@@ -1359,12 +1287,13 @@ __global__ __launch_bounds__(256, 7) void one_kernel(PassParams p)
             if (gl == 0)
                 w = atomicAdd(p.ctrl + CTL_WORK, 1ull);
             w = __shfl(w, gshift);
-            if (w >= (unsigned long long)p.n_reads) {
+            // LIST: the reads of a list made on the device (the few reads the lane-per-chunk pass handed back)
+            if (w >= (LIST ? *p.only_n : (unsigned long long)p.n_reads)) {
                 have = false;
                 return;
             }
             have = true;
-            r = (uint32_t)w;
+            r = LIST ? p.only[w] : (uint32_t)w;
             const uint64_t o0 = p.offsets[r], o1 = p.offsets[r + 1];
             if (p.in_staged) {
                 in = p.in + slot_of(o0, r, p.slack);
@@ -2007,6 +1936,26 @@ void launch_one(const PassParams &p, uint32_t blocks, hipStream_t s)
         one_kernel<G, 0><<<blocks, 256, 0, s>>>(p);
 }
 
+} // namespace
+
+namespace brx {
+// One's group kernel over the reads p.only[0 .. *p.only_n): what the lane-per-chunk pass could not stitch
+int launch_one_list(const PassParams &p, hipStream_t s)
+{
+    const uint32_t blocks = 128; // 4096 eight-lane groups; the list is a few reads, and the grid loops over it
+    if (p.k == 19)
+        one_kernel<8, 19, true><<<blocks, 256, 0, s>>>(p);
+    else if (p.k == 21)
+        one_kernel<8, 21, true><<<blocks, 256, 0, s>>>(p);
+    else
+        one_kernel<8, 0, true><<<blocks, 256, 0, s>>>(p);
+    BRX_HIP(hipGetLastError());
+    return BRX_OK;
+}
+} // namespace brx
+
+namespace {
+
 template <int M>
 int launch_method(const PassParams &p, int G, uint32_t blocks, size_t lds, hipStream_t s)
 {
@@ -2381,6 +2330,25 @@ static int correct_batch_device_locked(brx_chain_t *ch, const uint8_t *d_bases, 
                 p.path_k = ch->d_path;
                 p.maxpath = maxpath;
                 BRX_HIP(hipMemsetAsync(ch->d_ctrl + CTL_WORK, 0, 8, s));
+                p.flags = 0;
+                p.max_search = 0;
+                p.g_dim = 0;
+                p.g_lds_bytes = 0;
+                if (mth == BRX_ONE && dir == 0 && !p.flip) {
+                    // One's forward pass: one lane per chunk of a read (brx_onelane.hip) where that form applies
+                    const LanePassInfo info{cur_staged ? ch->stage_bytes : total_bases};
+                    const int lst = lane_pass(ch, p, info, s);
+                    if (lst != BRX_OK && lst != BRX_ERR_UNSUPPORTED)
+                        return lst;
+                    if (lst == BRX_OK) {
+                        cur = ch->d_stage[pp];
+                        cur_lens = ch->d_lens[pp];
+                        cur_staged = 1;
+                        cur_rev = dir;
+                        pp ^= 1;
+                        continue;
+                    }
+                }
                 int gw = dir ? group_width(true, false, n_reads) : G;
                 if (gw < 16 && mth != BRX_ONE) {
                     // the walking methods spend most of their rounds on one walk step = 4 probes: narrow groups keep the
@@ -2449,6 +2417,7 @@ static int correct_batch_device_locked(brx_chain_t *ch, const uint8_t *d_bases, 
                 continue;
             }
         }
+        stats[7] = (ch->h_ctrl[CTL_LANE_UNITS] & 0xffffffffull) | (ch->h_ctrl[CTL_LANE_FAIL] << 32);
         stats[0] += ch->h_ctrl[CTL_ROUNDS];
         stats[1] += ch->h_ctrl[CTL_PROBES];
         stats[2] += ch->h_ctrl[CTL_TRIGGERS];
@@ -2570,6 +2539,8 @@ void brx_chain_free(brx_chain_t *ch)
     if (ch->sub)
         brx_chain_free(ch->sub);
     ch->sub = nullptr;
+    if (use_device(ch->device) == BRX_OK)
+        lane_ws_free(ch);
     if (use_device(ch->device) == BRX_OK) {
         for (int q = 0; q < 2; q++) {
             if (ch->d_stage[q])

@@ -162,5 +162,6 @@ struct brx_chain {
     // whose graph walks outgrew the visited list; created on first need
     brx_chain *sub = nullptr;
     bool is_sub = false;
+    void *lane_ws = nullptr; // workspace of the lane-per-chunk pass (brx_onelane.hip)
     std::mutex mu;
 };

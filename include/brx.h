@@ -246,7 +246,9 @@ int brx_chain_correct_batch_device(brx_chain_t *chain, const uint8_t *d_bases, c
                                    uint64_t *d_out_offsets, uint64_t *out_total, void *stream);
 /* counters of the last batch: [0] scan rounds, [1] probes issued, [2] triggers, [3] fixes,
  * [4] overflow retries, [5] reads that outgrew their output slot and [6] graph walks that outgrew the
- * visited list in the attempts that were redone (u64[8], [7] reserved)                              */
+ * visited list in the attempts that were redone; [7] the last lane-per-chunk pass of correct::one (forward
+ * scan cut into units at predictable states): units in the low 32 bits, reads handed back to the
+ * group kernel because two predictions in a row missed in the high 32 bits; 0 = that form did not run        */
 int brx_chain_last_stats(const brx_chain_t *chain, uint64_t *stats8);
 void brx_chain_free(brx_chain_t *chain);
 void brx_buf_free(void *p);

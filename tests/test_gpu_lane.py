@@ -1,0 +1,120 @@
+"""correct::One's forward pass in its lane-per-chunk form (br_amd/csrc/brx_onelane.hip): a read is cut into units at
+sync points (positions behind R solid original k-mers in a row), every unit is scanned by one lane from the predicted
+state (i, original k-mer), the predecessor checks the prediction when it gets there, misses scan on into a second
+staging area, two misses hand the read back to the group kernel, and a stitch kernel joins the pieces.  Whatever the
+chunk length and the sync rule, the bytes are the sequential scan's (src/correct/mod.rs:53-107), i.e. the oracle's."""
+import os
+
+import numpy as np
+import pytest
+
+import br_amd
+from br_amd import _lib, synth
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture
+def lane_env(monkeypatch):
+    def set_(chunk=None, sync=None, lane=None):
+        for key, v in (("BRX_LANE_CHUNK", chunk), ("BRX_LANE_SYNC", sync), ("BRX_LANE", lane)):
+            if v is None:
+                monkeypatch.delenv(key, raising=False)
+            else:
+                monkeypatch.setenv(key, str(v))
+    return set_
+
+
+@pytest.mark.parametrize("chunk,sync", [(64, 1), (64, 4), (100, 2), (256, 4), (333, 8), (2048, 4), (None, None)])
+def test_fixture_reads_any_chunking(raw_reads, solid_fixture_bytes, lane_env, chunk, sync):
+    """the reference's fixture set (k = 11) on 80 reads of raw.fasta (3 - 62 kb), One alone and in front of Graph,
+    forward only and forward + reverse: byte parity for every chunk length / sync rule, and the units really ran"""
+    lane_env(chunk, sync)
+    reads = raw_reads[:80]
+    gs = br_amd.Pcon.from_pcon_solid(solid_fixture_bytes)
+    ref = O.Solid.from_bytes(solid_fixture_bytes)
+    for names, two_side in ((["one"], True), (["one"], False), (["one", "graph"], False), (["two", "one"], True)):
+        chain = br_amd.Chain(gs, [(m, 5, 7) for m in names], two_side=two_side)
+        got = chain.correct_reads(reads)
+        st = chain.last_stats()
+        om = O.build_methods(ref, names, 5, 7)
+        for r, g in zip(reads, got):
+            assert g == O.correct_record(om, r, two_side)
+        assert st["lane_units"] >= len(reads)
+        if chunk is not None and chunk <= 256:
+            assert st["lane_units"] > 20 * len(reads)
+        assert st["fixes"] > 0
+
+
+def test_lane_off_is_the_group_kernel(raw_reads, solid_fixture_bytes, lane_env):
+    lane_env(lane=0)
+    gs = br_amd.Pcon.from_pcon_solid(solid_fixture_bytes)
+    chain = br_amd.Chain(gs, [("one", 5, 7)], two_side=False)
+    a = chain.correct_reads(raw_reads[:30])
+    assert chain.last_stats()["lane_units"] == 0
+    lane_env()
+    chain2 = br_amd.Chain(gs, [("one", 5, 7)], two_side=False)
+    b = chain2.correct_reads(raw_reads[:30])
+    assert chain2.last_stats()["lane_units"] > 0 and a == b
+
+
+@pytest.mark.parametrize("k,confirm", [(13, 5), (15, 2), (19, 5), (19, 0), (21, 3), (25, 1)])
+def test_synthetic_reads_vs_oracle(lane_env, k, confirm):
+    """synthetic ONT-error reads (the bench's error model) against a counted set: dense / lazy / sparse holdings of the set
+    behind the same automaton, confirm 0 ... 5, short reads, reads shorter than k, an empty read"""
+    lane_env(128, 3)
+    cfg = synth.config(genome_len=40_000, read_len=3_000)
+    g = synth.genome_host(cfg)
+    bases, offs = synth.reads_host(cfg, g, 0, 500)
+    reads = [bases[int(offs[i]):int(offs[i + 1])].tobytes() for i in range(500)]
+    reads += [b"", b"ACGT", reads[0][:k - 1], reads[1][:k], reads[2][:k + 1], reads[3][:k + 7], reads[4][:130]]
+    if k <= 21:
+        gs = br_amd.Pcon.from_count(reads, k, 2)
+        ref = O.Solid.from_count(k, O.count_reads(k, reads), 2) if k <= 15 else O.Solid.sparse_from_count(k, reads, 2)
+    else:
+        gs = br_amd.Pcon.from_fasta(reads, k)
+        ref = O.Solid.sparse_from_count(k, reads, 0)
+    chain = br_amd.Chain(gs, [("one", confirm, 7)], two_side=False)
+    got = chain.correct_reads(reads)
+    om = O.build_methods(ref, ["one"], confirm, 7)
+    bad = [i for i, (r, x) in enumerate(zip(reads, got)) if x != O.correct_record(om, r, False)]
+    assert not bad, bad[:10]
+    st = chain.last_stats()
+    assert st["lane_units"] > 5_000 and st["lane_redone_reads"] < 50
+
+
+def test_confirm_beyond_the_window_takes_the_group_kernel(raw_reads, solid_fixture_bytes, lane_env):
+    """-C 9: the look-aheads do not fit the 8-base window of a lane's round, so the pass falls back as a whole"""
+    lane_env(100, 2)
+    gs = br_amd.Pcon.from_pcon_solid(solid_fixture_bytes)
+    ref = O.Solid.from_bytes(solid_fixture_bytes)
+    chain = br_amd.Chain(gs, [("one", 9, 7)], two_side=True)
+    got = chain.correct_reads(raw_reads[:20])
+    om = O.build_methods(ref, ["one"], 9, 7)
+    assert got == [O.correct_record(om, r, True) for r in raw_reads[:20]]
+    assert chain.last_stats()["lane_units"] == 0
+
+
+def test_growing_reads_and_slot_overflow(lane_env):
+    """a set in which every trigger resolves as a deletion makes reads GROW (one.rs:61: offset 0): units outgrow their
+    staging regions and reads their slots; both go back through the group kernel / the redo with more slack"""
+    lane_env(64, 1)
+    rng = np.random.default_rng(5)
+    k = 9
+    genome = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), 4000).tobytes()
+    reads = []
+    for _ in range(60):
+        s = int(rng.integers(0, 3000))
+        r = bytearray(genome[s:s + 900])
+        for pos in sorted(rng.integers(20, len(r) - 20, size=60).tolist(), reverse=True):
+            del r[pos]                                    # deletions only: the corrector puts the bases back
+        reads.append(bytes(r))
+    gs = br_amd.Pcon.from_fasta([genome], k)
+    ref = O.Solid(k)
+    ref.set_seq(genome)
+    chain = br_amd.Chain(gs, [("one", 2, 7)], two_side=True)
+    got = chain.correct_reads(reads)
+    om = O.build_methods(ref, ["one"], 2, 7)
+    assert got == [O.correct_record(om, r, True) for r in reads]
+    assert sum(len(x) for x in got) > sum(len(r) for r in reads)

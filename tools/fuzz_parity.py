@@ -72,7 +72,10 @@ while time.time() < t_end:
            # the LDS hash count of the partitioned finish: wrong guesses of the share of distinct keys and tiny tables
            "BRX_HF_RATIO": str(rng.choice(["", "", "0.01", "1"])), "BRX_HF_LOG_T": str(rng.choice(["", "", "6", "8"])),
            "BRX_HF_MIN_LT": str(rng.choice(["", "", "4"])), "BRX_WIDE_L2": str(rng.choice(["", "1", "0"])),
-           "BRX_HASH_FINAL": str(rng.choice(["", "", "0"]))}
+           "BRX_HASH_FINAL": str(rng.choice(["", "", "0"])),
+           # One's forward pass cut into units (brx_onelane.hip): off, tiny chunks, sync runs from sloppy to strict
+           "BRX_LANE": str(rng.choice(["", "", "", "0"])), "BRX_LANE_CHUNK": str(rng.choice(["", "64", "100", "333"])),
+           "BRX_LANE_SYNC": str(rng.choice(["", "1", "2", "8"]))}
     for key, v in env.items():
         if v == "":
             os.environ.pop(key, None)
