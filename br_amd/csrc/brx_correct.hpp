@@ -8,9 +8,9 @@ namespace brx {
 
 // control block layout (u64 words)
 enum { CTL_WORK = 0, CTL_OVERFLOW = 1, CTL_ROUNDS = 2, CTL_PROBES = 3, CTL_TRIGGERS = 4, CTL_FIXES = 5, CTL_TOTAL = 6, CTL_PATHOVF = 7, CTL_NONTERM = 8,
-       // the lane-per-chunk form of One's forward pass (brx_onelane.hip): units of the pass, bytes of its unit staging,
-       // its work counter, reads handed back to the group kernel, and their list's work counter
-       CTL_LANE_UNITS = 9, CTL_LANE_XBYTES = 10, CTL_LANE_WORK = 11, CTL_LANE_FAIL = 12, CTL_LANE_REDO = 13, CTL_LANE_VOID = 14,
+       // the lane-per-chunk form of One's forward pass (brx_onelane.hip): units of the pass, predictions that missed,
+       // its work counter, reads handed back to the group kernel
+       CTL_LANE_UNITS = 9, CTL_LANE_MISS = 10, CTL_LANE_WORK = 11, CTL_LANE_FAIL = 12,
        CTL_N = 16 };
 
 struct PassParams {

@@ -7,7 +7,7 @@
 // instructions per wave-round with 29 of 64 lanes live, because the eight groups of a wave sit in different states and
 // every wave runs the union of the states' code every round (profiles/r2h_sq_summary.json).  Here every lane is its own
 // scalar state machine over its own stretch of a read, written as ONE straight-line round -- build the k-mer this state
-// asks about, one KmerSet::get, one table-like transition, at most one byte out -- so that all 64 lanes of a wave do
+// asks about, one KmerSet::get, one table-like transition, at most one fix out -- so that all 64 lanes of a wave do
 // useful work in every instruction whatever states they are in.
 //
 // Where the parallelism comes from.  A scan is sequential inside a read (i, kmer, previous are loop carried), and 1e5
@@ -20,11 +20,19 @@
 // unit u+1 therefore starts at (q, original k-mer) speculatively while unit u is still running, and unit u CHECKS the
 // prediction when it gets there.  If its state at q is the predicted one, its output ends at q and unit u+1's begins
 // there: the concatenation is byte for byte the sequential scan.  If not (it jumped over q, or carries a corrected
-// base), it keeps scanning through the next unit's stretch into a second staging area and checks again at the sync
-// point after that; two misses in a row hand the read back to the group kernel.  No unit ever waits for another one:
-// all coupling is resolved afterwards by lane_stitch_kernel, which walks the chain of units of a read (which unit's
-// output is the truth up to where) and copies the pieces into the read's ordinary staging slot, so that everything
-// downstream (reverse pass, other methods, compaction, the redo of overflowing reads) is unchanged.
+// base), it keeps scanning through the next unit's stretch, writing a second list, and checks again at the sync point
+// after that; three misses in a row hand the read back to the group kernel.  No unit ever waits for another one: all
+// coupling is resolved afterwards by lane_apply_kernel, which walks the chain of units of a read (which unit's output
+// is the truth up to where) and writes the read's ordinary staging slot, so that everything downstream (reverse
+// pass, other methods, compaction, the redo of overflowing reads) is unchanged.
+//
+// What a lane touches.  458 752 resident lanes that each stream their own bytes thrash every cache level (first form of
+// this file: 70 ms; every round waited for an input line, an output line and an index line of its own).  So a lane
+// reads its stretch as 2-BIT CODES, 16 bases per dword, from a packed copy of the batch (lane_pack_kernel) through a
+// 32-base window it keeps in two registers, refilled one round ahead; and it writes no bases at all: its output is the
+// list of its FIXES (position, bases of the read consumed, corrected base: 4 bytes each, one per ~40 bases), which
+// lane_apply_kernel replays over the original bytes -- everything the scan copies through verbatim (mod.rs:91,100),
+// lowercase and non-ACGT bytes included, is copied from the input by that kernel, coalesced.
 #include "brx_correct.hpp"
 
 #include <stdlib.h>
@@ -37,55 +45,61 @@ int exclusive_scan_lens(const uint32_t *d_lens, uint32_t n, uint64_t *d_tmp, uin
                         unsigned long long *d_total, hipStream_t s);
 }
 
+
 namespace {
 
 constexpr uint32_t U_VOID = 0xffffffffu;   // u_q: the unit found no sync point (its predecessor scans through it)
-constexpr uint32_t U_END = 0xffffffffu;    // res[2] / res[3]: the target was the end of the read
-constexpr uint32_t C_MATCH1 = 0xfffffff0u; // res[3]: the unit's state matched at its first target
-constexpr uint32_t C_FAIL = 0xfffffff1u;   // res[3]: two misses, or a staging region overflowed: back to the group kernel
-constexpr uint32_t C_VOID = 0xfffffff2u;   // res[3]: nothing produced
+constexpr uint32_t U_END = 0xffffffffu;    // a target: the end of the read
+constexpr uint32_t C_FAIL = 0xfffffff1u;   // res[6]: three misses in a row, or an edit list overflowed: back to the group kernel
+constexpr uint32_t C_VOID = 0xfffffff2u;   // res[6]: nothing produced
+constexpr int MAX_DEPTH = 3;               // edit lists: own stretch + two stretches scanned after a miss
+constexpr uint32_t MAX_LANE_READ = 1u << 28; // positions are kept in 28 bits of an edit
 
 struct LaneArgs {
     PassParams p;
     uint32_t C;                // nominal chunk length
     uint32_t R;                // solid original k-mers in a row that make a sync point
     uint32_t *nu;              // units per read                            [n_reads]
-    uint32_t *xsz;             // bytes of unit staging per read            [n_reads]
     uint64_t *ubase;           // exclusive scan of nu                      [n_reads + 1]
-    uint64_t *xbase;           // exclusive scan of xsz                     [n_reads + 1]
     uint32_t *u_read;          // read of a unit                            [units]
     uint32_t *u_q;             // its sync position (0 for a read's first)  [units]
     uint64_t *u_qk;            // the original k-mer in front of it         [units]
-    uint32_t *u_res;           // len_own, len_cont, t1, code               [4 x units]
-    uint8_t *X, *Y;            // unit staging: own stretch / the stretch after a miss
+    uint32_t *u_res;           // n0 t1 n1 t2 n2 t3 code -                  [8 x units]
+    uint32_t *P;               // the batch as 2-bit codes, 16 bases per dword, first base in the top bits
+    uint32_t *E[MAX_DEPTH];    // edit lists: pos << 4 | consumed << 2 | base
     uint32_t *fail_list;       // reads handed back to the group kernel     [n_reads]
 };
 
-// where unit jj of a read, starting at position q, writes inside the read's share of X / Y.  Monotone in (jj, q); the
-// distance between two units' starts leaves the stretch between them room to grow by slack/4 and 64 bytes per unit.
-__device__ __forceinline__ uint64_t lane_region(uint64_t xb, uint32_t jj, uint32_t q, uint32_t slack)
-{
-    return xb + (uint64_t)q + (uint64_t)(q >> 2) * slack + 64ull * jj;
-}
-
-__device__ __forceinline__ void read_view(const PassParams &p, uint32_t r, const uint8_t *&in, uint32_t &n, bool &poisoned)
+// byte offset of read r's input in its buffer, its length (0 for a poisoned read)
+__device__ __forceinline__ uint64_t read_view(const PassParams &p, uint32_t r, const uint8_t *&in, uint32_t &n, bool &poisoned)
 {
     const uint64_t o0 = p.offsets[r], o1 = p.offsets[r + 1];
     poisoned = false;
+    uint64_t at;
     if (p.in_staged) {
-        in = p.in + slot_of(o0, r, p.slack);
+        at = slot_of(o0, r, p.slack);
         n = p.in_lens[r];
         if (n == 0xffffffffu) {
             poisoned = true;
             n = 0;
         }
     } else {
-        in = p.in + o0;
+        at = o0;
         n = (uint32_t)(o1 - o0);
     }
+    in = p.in + at;
+    return at;
+}
+// first dword of read r in P: 16 bases per dword and five dwords of padding per read (the window prefetches ahead)
+__device__ __forceinline__ uint64_t pack_start(uint64_t in_at, uint32_t r) { return (in_at >> 4) + 5ull * r; }
+// first entry of unit jj (sync position q) of a read in an edit list: a quarter entry per base + 16 per unit.  Monotone
+// in (read, jj, q), so the distance to the next unit's start is this unit's capacity.
+__device__ __forceinline__ uint64_t edit_start(uint64_t in_at, uint32_t r, uint64_t ub, uint32_t jj, uint32_t q)
+{
+    return (in_at >> 2) + 16ull * (ub + r + jj) + (uint64_t)(q >> 2);
 }
 
-// ---- unit tables ------------------------------------------------------------------------------------------------------
+// ---- unit tables, packed copy ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void lane_units_kernel(LaneArgs a)
 {
     const uint32_t r = blockIdx.x * 256u + threadIdx.x;
@@ -94,20 +108,45 @@ __global__ __launch_bounds__(256) void lane_units_kernel(LaneArgs a)
     const uint8_t *in;
     uint32_t n;
     bool poisoned;
-    read_view(a.p, r, in, n, poisoned);
-    const uint32_t nu = n < 2u * a.C ? 1u : n / a.C; // the last unit takes the remainder
-    a.nu[r] = nu;
-    a.xsz[r] = n + (n >> 2) * a.p.slack + 64u * nu + 64u;
+    (void)read_view(a.p, r, in, n, poisoned);
+    a.nu[r] = n < 2u * a.C ? 1u : n / a.C; // the last unit takes the remainder
 }
 
-__global__ __launch_bounds__(256) void lane_fill_kernel(LaneArgs a)
+__global__ __launch_bounds__(256) void lane_pack_kernel(LaneArgs a)
 {
-    const uint32_t r = blockIdx.x * 256u + threadIdx.x;
-    if (r >= a.p.n_reads)
-        return;
-    const uint64_t b = a.ubase[r], e = a.ubase[r + 1];
-    for (uint64_t u = b; u < e; u++)
-        a.u_read[u] = r;
+    for (uint32_t r = blockIdx.x; r < a.p.n_reads; r += gridDim.x) {
+        const uint8_t *in;
+        uint32_t n;
+        bool poisoned;
+        const uint64_t at = read_view(a.p, r, in, n, poisoned);
+        uint32_t *dst = a.P + pack_start(at, r);
+        const uint32_t ndw = (n >> 4) + 5u;
+        for (uint32_t d = threadIdx.x; d < ndw; d += 256) {
+            const uint32_t b = 16u * d;
+            uint32_t w[4] = {0, 0, 0, 0};
+            if (b + 16u <= n) {
+                uint4 q;
+                __builtin_memcpy(&q, in + b, 16);
+                w[0] = q.x;
+                w[1] = q.y;
+                w[2] = q.z;
+                w[3] = q.w;
+            } else {
+                for (uint32_t t = 0; t < 16u && b + t < n; t++)
+                    w[t >> 2] |= (uint32_t)in[b + t] << (8u * (t & 3u));
+            }
+            // bytes b0..b3 of a word (b0 = first base) -> b0<<6 | b1<<4 | b2<<2 | b3 by one multiply
+            uint32_t v = 0;
+#pragma unroll
+            for (int t = 0; t < 4; t++)
+                v = (v << 8) | ((((w[t] >> 1) & 0x03030303u) * 0x40100401u) >> 24);
+            dst[d] = v;
+        }
+        // and the read's units
+        const uint64_t ub = a.ubase[r], ue = a.ubase[r + 1];
+        for (uint64_t u = ub + threadIdx.x; u < ue; u += 256)
+            a.u_read[u] = r;
+    }
 }
 
 // KmerSet::get of one forward k-mer, whatever holds the set (src/set/pcon.rs:189-191)
@@ -152,7 +191,7 @@ __global__ __launch_bounds__(256) void lane_sync_kernel(LaneArgs a)
         const uint8_t *in;
         uint32_t n;
         bool poisoned;
-        read_view(p, r, in, n, poisoned);
+        (void)read_view(p, r, in, n, poisoned);
         const uint32_t s = j * a.C;
         const uint32_t lim = (s + a.C < n) ? s + a.C : n; // k-mers ending at e < lim
         uint32_t q = U_VOID;
@@ -188,332 +227,331 @@ __global__ __launch_bounds__(256) void lane_sync_kernel(LaneArgs a)
 }
 
 // ---- the automaton ----------------------------------------------------------------------------------------------------
-enum { L_SCAN = 0, L_ALTS = 1, L_SCEN = 2, L_MORE = 3, L_FIRST = 4 };
+// One round of one lane = one KmerSet::get and the transition it decides.  The round is written as straight-line code
+// over a PACKED state word, so that the 64 lanes of a wave -- each in a state of its own -- share every instruction;
+// what is rare (a unit ends, a new one is fetched, a read ends within eight bases) sits in branches a wave skips.
+//   st    0 SCAN  probe add(kmer, seq[i])                   mod.rs:69-73     (`first`: probe kmer itself, mod.rs:67)
+//         1 ALTS  probe the trigger k-mer with last base cur   mod.rs:114-128 (the read's own base is known not solid)
+//         2 SCEN  probe corr + seq[off .. off+jj]            exist/mod.rs:33-41  (scenario cur: I / S / D, off = 2 - cur)
+//         3 MORE  probe corr + seq[off .. off+c]             exist/mod.rs:57-66
+enum { S_ST = 0, S_CUR = 2, S_JJ = 4, S_AM = 8, S_PASS = 12, S_FAILM = 16, S_KEEP = 20, S_SKIP = 24, S_PREV = 27, S_FIRST = 28, S_SLOW = 29 };
 
 template <bool IDX, int KT>
 __global__ __launch_bounds__(256, 7) void lane_kernel(LaneArgs a)
 {
     const PassParams &p = a.p;
     const int k = KT ? KT : p.k;
-    const uint32_t c = (uint32_t)p.c;
+    const uint32_t c = (uint32_t)p.c; // 1 .. 5
     const uint64_t mask = kmask(k);
     const unsigned long long n_units = p.ctrl[CTL_LANE_UNITS];
+    // the index line a lane probed last, kept in LDS (element e of lane t at [e][t]: conflict-free 16-byte accesses):
+    // consecutive k-mers of a read share their minimizer for ~3 positions, and a line fetched per lane per round is what
+    // made the first form of this kernel wait for the L2 fabric
+    __shared__ uint4 lc[4][256];
+    const uint32_t tid = threadIdx.x;
 
     // the unit
-    bool have = false;
-    uint32_t u = 0, r = 0, n = 0, i = 0, tgt = 0, t1 = U_END, t1_first = U_END, uend = 0, nu_r = 0;
-    uint64_t ub = 0, xb = 0, tgtk = 0;
-    const uint8_t *in = nullptr;
-    uint8_t *out = nullptr;
-    uint32_t olen = 0, cap = 0, len_own = 0, phase = 0;
+    bool have = false, want = true;
+    uint32_t u = 0, r = 0, n = 0, i = 0, tgt = 0, t1 = U_END;
+    uint64_t tgtk = 0;
+    uint32_t depth = 0, ne = 0, ecap = 0;
+    uint64_t eat = 0; // first entry of the edit list being written
+    // the bases ahead: positions i .. i+wcnt of the read, 2 bits each, position i in the top bits; the next 16 in nextw
+    uint64_t wreg = 0;
+    uint32_t wcnt = 0, nextw = 0, pidx = 0;
     // the scan (mod.rs:60-67) and the trigger in progress
     uint64_t kmer = 0, corr = 0;
-    bool prev = false;
-    uint32_t st = L_SCAN, cur = 0 /* alternative / scenario being asked about */, jj = 0, am = 0, passm = 0, failm = 0, keep = 0, skip = 0;
-    uint32_t hop = 0;
-    bool slowbits = false;
-    uint32_t n_rounds = 0, n_probes = 0, n_trig = 0, n_fix = 0;
+    uint32_t S = 0, hop = 0, cline = 0xffffffffu;
+    uint32_t n_rounds = 0, n_probes = 0, n_trig = 0, n_fix = 0, n_miss = 0; // wave-uniform (scalar registers)
 
+    // where the edits of unit jj (sync position q) of this lane's read start
+    auto unit_edits = [&](uint32_t jj, uint32_t q) {
+        const uint8_t *in;
+        uint32_t nn;
+        bool poisoned;
+        const uint64_t in_at = read_view(p, r, in, nn, poisoned);
+        return edit_start(in_at, r, a.ubase[r], jj, q);
+    };
+    // the next unit of this read at or after `from` that has a sync point (none: the end of the read) becomes the
+    // target; returns where its edits start = where this stretch's list must end
     auto set_target = [&](uint32_t from) {
-        // the next unit of this read that has a sync point; none: the end of the read
+        const uint32_t ubl = (uint32_t)a.ubase[r], uend = (uint32_t)a.ubase[r + 1];
         uint32_t t = from;
         while (t < uend && a.u_q[t] == U_VOID)
             t++;
-        uint64_t end_at;
         if (t < uend) {
             t1 = t;
             tgt = a.u_q[t];
             tgtk = a.u_qk[t];
-            end_at = lane_region(xb, t - (uint32_t)ub, tgt, p.slack);
-        } else {
-            t1 = U_END;
-            tgt = n;
-            tgtk = 0;
-            end_at = lane_region(xb, nu_r, n, p.slack);
+            return unit_edits(t - ubl, tgt);
         }
-        return end_at;
-    };
-    auto record = [&](uint32_t l0, uint32_t l1, uint32_t tt, uint32_t code) {
-        uint4 v = make_uint4(l0, l1, tt, code);
-        *reinterpret_cast<uint4 *>(a.u_res + 4ull * u) = v;
-    };
-    auto fetch = [&]() {
-        for (;;) {
-            const unsigned long long w = atomicAdd(p.ctrl + CTL_LANE_WORK, 1ull);
-            if (w >= n_units) {
-                have = false;
-                return;
-            }
-            have = true;
-            u = (uint32_t)w;
-            r = a.u_read[u];
-            ub = a.ubase[r];
-            uend = (uint32_t)a.ubase[r + 1];
-            nu_r = uend - (uint32_t)ub;
-            xb = a.xbase[r];
-            const uint32_t j = u - (uint32_t)ub;
-            bool poisoned;
-            read_view(p, r, in, n, poisoned);
-            const uint32_t q = a.u_q[u];
-            if (q == U_VOID) {
-                record(0, 0, U_END, C_VOID);
-                continue;
-            }
-            const uint64_t start = lane_region(xb, j, q, p.slack);
-            out = a.X + start;
-            const uint64_t end_at = set_target(u + 1u);
-            cap = (uint32_t)(end_at - start);
-            phase = 0;
-            olen = 0;
-            hop = 0;
-            slowbits = false;
-            skip = 0;
-            if (j == 0) {
-                if (n < (uint32_t)k) {
-                    // mod.rs:56-58: shorter than k, returned verbatim (a read's only unit: n < 2C)
-                    for (uint32_t t = 0; t < n; t++)
-                        out[t] = in[t];
-                    record(n, 0, U_END, C_MATCH1);
-                    continue;
-                }
-                uint64_t km = 0;
-                for (int t = 0; t < k; t++) {
-                    const uint8_t b = in[t];
-                    km = (km << 2) | nuc2bit(b);
-                    out[t] = b;
-                }
-                kmer = km;
-                olen = (uint32_t)k;
-                i = (uint32_t)k;
-                st = L_FIRST; // previous = get(kmer), mod.rs:67
-            } else {
-                i = q;
-                kmer = a.u_qk[u];
-                prev = true; // R >= 1 solid k-mers end in front of q
-                st = L_SCAN;
-            }
-            return;
-        }
+        t1 = U_END;
+        tgt = n;
+        tgtk = 0;
+        return unit_edits(uend - ubl, n);
     };
 
-    fetch();
-    while (__any(have)) {
-        // ---- a unit ends where the scan reaches its target (loop top, mod.rs:68) -------------------------------------
-        if (have && st == L_SCAN && i >= tgt) {
-            if (t1 == U_END || (i == tgt && kmer == tgtk)) {
-                if (phase == 0)
-                    record(olen, 0, t1, C_MATCH1);
-                else
-                    record(len_own, olen, t1_first, t1);
-                fetch();
-            } else if (phase == 0) {
-                // the prediction did not hold: keep scanning, through the next unit's stretch, into Y
-                phase = 1;
-                len_own = olen;
-                t1_first = t1;
-                const uint64_t start = lane_region(xb, t1 - (uint32_t)ub, tgt, p.slack);
-                out = a.Y + start;
-                olen = 0;
-                const uint64_t end_at = set_target(t1 + 1u);
-                cap = (uint32_t)(end_at - start);
-            } else {
-                record(len_own, olen, t1_first, C_FAIL);
-                fetch();
+    for (;;) {
+        // ---- rare: a unit ends where the scan reaches its target (loop top, mod.rs:68); units are handed out --------
+        uint32_t ev = 0; // this lane's events of the round: 1 probe, 2 trigger, 4 fix, 8 missed prediction
+        const bool at_end = have && (S & 3u) == 0u && i >= tgt;
+        if (__any(at_end || want)) {
+            uint32_t *res = a.u_res + 8ull * u;
+            if (at_end) {
+                res[2 * depth] = ne;
+                res[2 * depth + 1] = t1;
+                if (t1 == U_END || (i == tgt && kmer == tgtk)) {
+                    res[6] = depth;
+                    want = true;
+                } else if (depth + 1 < (uint32_t)MAX_DEPTH) {
+                    // the prediction did not hold: keep scanning through the next unit's stretch, into the next list
+                    ev |= 8u;
+                    depth++;
+                    eat = unit_edits(t1 - (uint32_t)a.ubase[r], tgt);
+                    ne = 0;
+                    ecap = (uint32_t)(set_target(t1 + 1u) - eat);
+                } else {
+                    res[6] = C_FAIL;
+                    want = true;
+                }
             }
+            while (want) { // ONE place where a lane takes a new unit
+                const unsigned long long w = atomicAdd(p.ctrl + CTL_LANE_WORK, 1ull);
+                want = false;
+                have = w < n_units;
+                if (!have)
+                    break;
+                u = (uint32_t)w;
+                res = a.u_res + 8ull * u;
+                r = a.u_read[u];
+                const uint32_t j = u - (uint32_t)a.ubase[r];
+                const uint8_t *in;
+                bool poisoned;
+                const uint64_t in_at = read_view(p, r, in, n, poisoned);
+                const uint32_t q = a.u_q[u];
+                if (q == U_VOID || n >= MAX_LANE_READ) {
+                    res[6] = q == U_VOID ? C_VOID : C_FAIL;
+                    want = true;
+                    continue;
+                }
+                eat = unit_edits(j, q);
+                ecap = (uint32_t)(set_target(u + 1u) - eat);
+                depth = 0;
+                ne = 0;
+                hop = 0;
+                // the window at q
+                const uint64_t pw = pack_start(in_at, r) + (q >> 4);
+                wreg = (((uint64_t)a.P[pw] << 32) | a.P[pw + 1]) << ((q & 15u) * 2u);
+                wcnt = 32u - (q & 15u);
+                nextw = a.P[pw + 2];
+                pidx = (uint32_t)pw + 3u;
+                if (j == 0) {
+                    if (n < (uint32_t)k) { // mod.rs:56-58: returned verbatim, i.e. no edits
+                        res[0] = 0;
+                        res[1] = U_END;
+                        res[6] = 0;
+                        want = true;
+                        continue;
+                    }
+                    kmer = wreg >> (64 - 2 * k);
+                    wreg <<= 2 * k; // k <= 31
+                    wcnt -= (uint32_t)k;
+                    i = (uint32_t)k;
+                    S = 1u << S_FIRST; // previous = get(kmer), mod.rs:67: SCAN that probes kmer itself; prev = false accepts it
+                } else {
+                    i = q;
+                    kmer = a.u_qk[u];
+                    S = 1u << S_PREV; // R >= 1 solid k-mers end in front of q
+                }
+            }
+            if (!__any(have))
+                break;
         }
         // (a lane that just missed its target takes part in this round only if it still is in front of the next one)
-        const bool act = have && !(st == L_SCAN && i >= tgt);
+        const bool act = have && !((S & 3u) == 0u && i >= tgt);
+        n_rounds += (uint32_t)__builtin_popcountll(__ballot(act));
         if (act) {
-            n_rounds++;
-            // ---- the next bases: in[i .. i+8), 2 bits each, first base in bits 15:14 ------------------------------------
-            uint64_t w8 = 0;
-            if (i + 8u <= n) {
-                __builtin_memcpy(&w8, in + i, 8);
-            } else {
-                for (uint32_t t = 0; t < 8u && i + t < n; t++)
-                    w8 |= (uint64_t)in[i + t] << (8u * t);
+            if (wcnt <= 16u) { // (the dword was loaded at the refill before this one)
+                wreg |= (uint64_t)nextw << (32u - 2u * wcnt);
+                wcnt += 16u;
+                nextw = a.P[pidx];
+                pidx++;
             }
-            const uint32_t wlo = (uint32_t)w8, whi = (uint32_t)(w8 >> 32);
-            const uint32_t cw = (((((wlo >> 1) & 0x03030303u) * 0x40100401u) >> 24) << 8) | ((((whi >> 1) & 0x03030303u) * 0x40100401u) >> 24);
-            const uint32_t c0 = cw >> 14; // code of in[i]
+            const uint32_t cw = (uint32_t)(wreg >> 48); // seq[i .. i+8), first base in bits 15:14
+            const uint32_t c0 = cw >> 14;               // seq[i]
+            const uint32_t st = S & 3u, cur = (S >> S_CUR) & 3u, jj = (S >> S_JJ) & 7u, skip = (S >> S_SKIP) & 7u;
+            const bool prev = (S >> S_PREV) & 1u, first = (S >> S_FIRST) & 1u, slow = (S >> S_SLOW) & 1u;
             const uint32_t rem = n - i;
 
             // ---- the k-mer this state asks about ------------------------------------------------------------------------
-            // SCAN: add(kmer, seq[i]); FIRST: kmer; ALTS: the trigger k-mer with its last base replaced (mod.rs:114-128);
-            // SCEN: corr + seq[off .. off+j] (exist/mod.rs:33-41); MORE: corr + seq[off .. off+c] (exist/mod.rs:57-66)
             const uint32_t off = 2u - cur; // I:2 S:1 D:0 (one.rs:57-63); meaningful in SCEN / MORE only
-            const bool on_corr = st == L_ALTS || st == L_SCEN || st == L_MORE;
-            const uint32_t nb = st == L_SCAN ? 1u : (st == L_SCEN ? jj + 1u : (st == L_MORE ? c + 1u : 0u));
-            const uint32_t b0 = (st == L_SCEN || st == L_MORE) ? off : 0u;
+            const uint32_t nb = st == 0u ? (first ? 0u : 1u) : (st == 2u ? jj + 1u : (st == 3u ? c + 1u : 0u));
+            const uint32_t b0 = st >= 2u ? off : 0u;
             const uint32_t wbits = (cw >> (16u - 2u * (b0 + nb))) & ((1u << (2u * nb)) - 1u);
-            uint64_t pk = (((on_corr ? corr : kmer) << (2u * nb)) | (uint64_t)wbits) & mask;
-            if (st == L_ALTS)
+            uint64_t pk = (((st == 0u ? kmer : corr) << (2u * nb)) | (uint64_t)wbits) & mask;
+            if (st == 1u)
                 pk = (pk & ~3ull) | (uint64_t)cur;
             // a base accepted behind a fix is known solid (it was a look-ahead of the winning scenario); a tie-break
             // that cannot read one base more is false without a probe (exist/mod.rs:54)
-            const bool need = !(st == L_SCAN && skip != 0u) && !(st == L_MORE && !(rem > c + off + 1u));
+            const bool need = !(st == 0u && skip != 0u) && !(st == 3u && !(rem > c + off + 1u));
+            ev |= need ? 1u : 0u;
 
             // ---- KmerSet::get -------------------------------------------------------------------------------------------
-            bool sol = (st == L_SCAN) && !need, unres = false;
-            if (need) {
-                n_probes++;
-                if (IDX) {
-                    uint64_t key;
-                    const uint32_t home = index_locate(p.idx, pk, k, key);
-                    if (!slowbits) {
-                        const int pr = index_probe_at(p.idx, key, home, hop);
-                        sol = pr == 1;
-                        unres = pr == 2;
-                    } else { // the home line overflowed at build time and does not hold the key: the bit vector knows
-                        const uint64_t h = key - 1ull;
-                        sol = (p.bits[h >> 5] >> (h & 31u)) & 1u;
-                    }
-                } else {
-                    sol = probe(p.bits, pk, k);
+            bool sol = (st == 0u) && !need, unres = false;
+            if (IDX) {
+                uint64_t key;
+                const uint32_t home = index_locate(p.idx, pk, k, key);
+                const uint32_t line = (home + hop) & (0xffffffffu >> p.idx.line_shift);
+                if (need && !slow && line != cline) { // not the line this lane holds: fetch it, keep it
+                    const uint4 *L = reinterpret_cast<const uint4 *>(p.idx.lines + (uint64_t)line * 8ull);
+                    const uint4 q0 = L[0], q1 = L[1], q2 = L[2], q3 = L[3];
+                    lc[0][tid] = q0;
+                    lc[1][tid] = q1;
+                    lc[2][tid] = q2;
+                    lc[3][tid] = q3;
+                    cline = line;
                 }
+                if (need && slow) { // the home line overflowed at build time and does not hold the key: the bit vector knows
+                    const uint64_t h = key - 1ull;
+                    sol = (p.bits[h >> 5] >> (h & 31u)) & 1u;
+                } else if (need) {
+                    const uint4 q0 = lc[0][tid], q1 = lc[1][tid], q2 = lc[2][tid], q3 = lc[3][tid];
+                    const uint32_t klo = (uint32_t)key, khi = (uint32_t)(key >> 32);
+                    const bool found = ((q0.x == klo) & (q0.y == khi)) | ((q0.z == klo) & (q0.w == khi)) | ((q1.x == klo) & (q1.y == khi)) |
+                                       ((q1.z == klo) & (q1.w == khi)) | ((q2.x == klo) & (q2.y == khi)) | ((q2.z == klo) & (q2.w == khi)) |
+                                       ((q3.x == klo) & (q3.y == khi));
+                    // home line (hop 0): go on only if one of the keys it turned away had this key's signature; further
+                    // down a chain only the flag can tell (brx_index.hpp: index_probe_at)
+                    const uint32_t hdr_hi = q3.w;
+                    const bool more = (hdr_hi >> 31) && (hop != 0u || ((hdr_hi >> idx_sig_index(key)) & 1u));
+                    sol = found;
+                    unres = !found && more;
+                }
+            } else if (need) {
+                sol = probe(p.bits, pk, k);
             }
             if (unres) {
                 // ask again next round: the bit vector, or (sparse sets) the next line of the chain
                 if (p.bits)
-                    slowbits = true;
+                    S |= 1u << S_SLOW;
                 else
                     hop++;
             } else {
-                slowbits = false;
                 hop = 0;
                 // ---- transition ---------------------------------------------------------------------------------------------
-                bool push = false, fail = false;
+                uint32_t T = S & ~(1u << S_SLOW);
+                bool fail = false;
                 int apply = -1;
-                uint8_t pb = (uint8_t)w8; // seq[i]
                 uint32_t adv = 0;
-                if (st == L_SCAN) {
-                    if (sol || !prev) { // mod.rs:99-102
-                        push = true;
-                        adv = 1;
+                if (st == 0u) {
+                    if (sol || !prev) { // mod.rs:99-102 (and mod.rs:67 for `first`)
+                        adv = first ? 0u : 1u;
                         kmer = pk;
-                        prev = sol;
-                        skip = skip ? skip - 1u : 0u;
+                        T = (T & ~((1u << S_PREV) | (1u << S_FIRST) | (7u << S_SKIP))) | ((sol ? 1u : 0u) << S_PREV) |
+                            ((skip ? skip - 1u : 0u) << S_SKIP);
                     } else { // mod.rs:73: the first k-mer that is not solid after a solid one
                         corr = pk;
-                        am = 0;
-                        cur = c0 == 0u ? 1u : 0u; // the read's own base IS the trigger k-mer: known not solid
-                        st = L_ALTS;
-                        n_trig++;
+                        // am = 0; the read's own base IS the trigger k-mer, known not solid: start at the other end
+                        T = (T & ~((15u << S_AM) | (3u << S_CUR) | 3u)) | 1u | ((c0 == 0u ? 1u : 0u) << S_CUR);
+                        ev |= 2u;
                     }
-                } else if (st == L_FIRST) {
-                    prev = sol;
-                    st = L_SCAN;
-                } else if (st == L_ALTS) {
-                    am |= (sol ? 1u : 0u) << cur;
+                } else if (st == 1u) {
+                    const uint32_t am = ((T >> S_AM) & 15u) | ((sol ? 1u : 0u) << cur);
                     uint32_t an = cur + 1u;
                     an += (an == c0) ? 1u : 0u;
+                    T = (T & ~((15u << S_AM) | (3u << S_CUR))) | (am << S_AM) | ((an & 3u) << S_CUR);
                     if (an >= 4u || __popc(am) > 1) {
                         if (__popc(am) == 1) { // exist/mod.rs:121-129
                             corr = (corr & ~3ull) | (uint64_t)(__ffs(am) - 1);
-                            failm = 0;
-                            for (uint32_t s = 0; s < 3u; s++)
-                                if ((2u - s) + c > rem) // exist/mod.rs:27-29
-                                    failm |= 1u << s;
-                            passm = 0;
+                            // scenarios that cannot read their c look-aheads (exist/mod.rs:27-29): I needs c+2, S c+1, D c
+                            const uint32_t failm = rem >= c + 2u ? 0u : (rem == c + 1u ? 1u : (rem == c ? 3u : 7u));
                             if (failm == 7u) {
                                 fail = true;
-                            } else if (c == 0u) { // every scenario scores 0 == c
-                                passm = 7u & ~failm;
-                                if (__popc(passm) == 1) {
-                                    apply = __ffs(passm) - 1;
-                                } else {
-                                    st = L_MORE;
-                                    cur = (uint32_t)__ffs(passm) - 1u;
-                                    keep = 0;
-                                }
                             } else {
-                                cur = (uint32_t)__ffs(7u & ~failm) - 1u;
-                                jj = 0;
-                                st = L_SCEN;
+                                const uint32_t s0 = (uint32_t)__ffs(7u & ~failm) - 1u;
+                                T = (T & ~((7u << S_FAILM) | (7u << S_PASS) | (7u << S_JJ) | (3u << S_CUR) | 3u)) | 2u | (s0 << S_CUR) |
+                                    (failm << S_FAILM);
                             }
                         } else {
                             fail = true; // exist/mod.rs:123-126
                         }
-                    } else {
-                        cur = an;
                     }
-                } else if (st == L_SCEN) {
-                    bool over = false;
+                } else if (st == 2u) {
+                    uint32_t passm = (T >> S_PASS) & 7u, failm = (T >> S_FAILM) & 7u;
+                    bool over = !sol;
                     if (sol) {
-                        jj++;
-                        if (jj == c) { // get_score == c
+                        if (jj + 1u == c) { // get_score == c
                             passm |= 1u << cur;
                             over = true;
                         }
                     } else { // exist/mod.rs:38-42: the score stops below c
                         failm |= 1u << cur;
-                        over = true;
                     }
+                    T = (T & ~((7u << S_PASS) | (7u << S_FAILM) | (7u << S_JJ))) | (passm << S_PASS) | (failm << S_FAILM) |
+                        ((over ? 0u : jj + 1u) << S_JJ);
                     if (over) {
                         const uint32_t rest = 7u & ~failm & ~passm & ~((2u << cur) - 1u);
                         if (rest) {
-                            cur = (uint32_t)__ffs(rest) - 1u;
-                            jj = 0;
+                            T = (T & ~(3u << S_CUR)) | (((uint32_t)__ffs(rest) - 1u) << S_CUR);
                         } else if (passm == 0u) {
                             fail = true; // exist/mod.rs:132-134
                         } else if (__popc(passm) == 1) {
                             apply = __ffs(passm) - 1; // exist/mod.rs:135-137
-                        } else {
-                            st = L_MORE;
-                            cur = (uint32_t)__ffs(passm) - 1u;
-                            keep = 0;
+                        } else { // several scenarios scored c: one base more decides (exist/mod.rs:138-147)
+                            T = (T & ~((7u << S_KEEP) | (3u << S_CUR) | 3u)) | 3u | (((uint32_t)__ffs(passm) - 1u) << S_CUR);
                         }
                     }
-                } else { // L_MORE, exist/mod.rs:138-147
-                    keep |= (sol ? 1u : 0u) << cur;
+                } else {
+                    const uint32_t passm = (T >> S_PASS) & 7u;
+                    const uint32_t keep = ((T >> S_KEEP) & 7u) | ((sol ? 1u : 0u) << cur);
+                    T = (T & ~(7u << S_KEEP)) | (keep << S_KEEP);
                     const uint32_t rest = passm & ~((2u << cur) - 1u);
                     if (rest)
-                        cur = (uint32_t)__ffs(rest) - 1u;
+                        T = (T & ~(3u << S_CUR)) | (((uint32_t)__ffs(rest) - 1u) << S_CUR);
                     else if (__popc(keep) == 1)
                         apply = __ffs(keep) - 1;
                     else
                         fail = true;
                 }
-                if (fail) { // mod.rs:91-96: the trigger base is copied through, the k-mer keeps it
-                    push = true;
+                if (fail) { // mod.rs:91-96: the trigger base is copied through, the k-mer keeps it; previous = false
                     adv = 1;
-                    prev = false;
                     kmer = (corr & ~3ull) | (uint64_t)c0;
-                    st = L_SCAN;
+                    T &= ~((1u << S_PREV) | 3u);
                 }
-                if (apply >= 0) { // mod.rs:75-89 with one.rs:65-71
-                    push = true;
-                    pb = bit2nuc(corr & 3ull);
-                    kmer = corr;
-                    prev = true;
-                    adv = 2u - (uint32_t)apply;
-                    // the c look-ahead k-mers of the winning scenario ARE the next c scan k-mers, all found solid: the
-                    // reference's loop copies these bases with previous = true (mod.rs:99-102); no second probe
-                    skip = c;
-                    st = L_SCAN;
-                    n_fix++;
-                }
-                if (push) {
-                    if (olen < cap) {
-                        out[olen] = pb;
-                        olen++;
-                    } else { // the stretch outgrew its staging region: the read goes back to the group kernel
-                        record(phase ? len_own : olen, phase ? olen : 0u, phase ? t1_first : t1, C_FAIL);
-                        fetch();
-                        adv = 0;
+                if (apply >= 0) { // mod.rs:75-89 with one.rs:65-71: one base out, `used` bases of the read consumed
+                    const uint32_t used = 2u - (uint32_t)apply;
+                    if (ne < ecap) {
+                        a.E[depth][eat + ne] = (i << 4) | (used << 2) | (uint32_t)(corr & 3ull);
+                        ne++;
+                        ev |= 4u;
+                        // The c look-ahead k-mers of the winning scenario ARE the next c scan k-mers, all found solid: the
+                        // reference's loop copies these bases with previous = true (mod.rs:99-102).  Jump over them -- unless
+                        // the unit's target lies among them: then they are walked one by one (without a probe), so that the
+                        // state at the target is seen
+                        const bool jump = tgt - i > used + c;
+                        const uint32_t cb = (cw >> (16u - 2u * (used + c))) & ((1u << (2u * c)) - 1u);
+                        kmer = jump ? (((corr << (2u * c)) | (uint64_t)cb) & mask) : corr;
+                        adv = used + (jump ? c : 0u);
+                        T = (T & ~((7u << S_SKIP) | 3u)) | (1u << S_PREV) | ((jump ? 0u : c) << S_SKIP);
+                    } else { // more fixes than the list holds: the read goes back to the group kernel
+                        a.u_res[8ull * u + 6] = C_FAIL;
+                        have = false;
+                        want = true;
                     }
                 }
+                S = T;
                 i += adv;
+                wreg <<= 2u * adv;
+                wcnt -= adv;
             }
         }
+        // every lane back together: count the round's events
+        n_probes += (uint32_t)__builtin_popcountll(__ballot(ev & 1u));
+        n_trig += (uint32_t)__builtin_popcountll(__ballot(ev & 2u));
+        n_fix += (uint32_t)__builtin_popcountll(__ballot(ev & 4u));
+        n_miss += (uint32_t)__builtin_popcountll(__ballot(ev & 8u));
     }
     // statistics: one atomic per wave per counter
-    for (int o = 32; o > 0; o >>= 1) {
-        n_rounds += __shfl_xor(n_rounds, o);
-        n_probes += __shfl_xor(n_probes, o);
-        n_trig += __shfl_xor(n_trig, o);
-        n_fix += __shfl_xor(n_fix, o);
-    }
     if ((threadIdx.x & 63) == 0) {
         if (n_rounds)
             atomicAdd(p.ctrl + CTL_ROUNDS, (unsigned long long)n_rounds);
@@ -523,10 +561,11 @@ __global__ __launch_bounds__(256, 7) void lane_kernel(LaneArgs a)
             atomicAdd(p.ctrl + CTL_TRIGGERS, (unsigned long long)n_trig);
         if (n_fix)
             atomicAdd(p.ctrl + CTL_FIXES, (unsigned long long)n_fix);
+        if (n_miss)
+            atomicAdd(p.ctrl + CTL_LANE_MISS, (unsigned long long)n_miss);
     }
 }
 
-// ---- stitch: the chain of units of a read -> its staging slot --------------------------------------------------------
 __device__ __forceinline__ void copy_bytes(uint8_t *dst, const uint8_t *src, uint32_t n)
 {
     // bytes up to the first 16-byte boundary of dst, then 16 bytes per lane (unaligned load, aligned store), then the tail
@@ -546,51 +585,187 @@ __device__ __forceinline__ void copy_bytes(uint8_t *dst, const uint8_t *src, uin
         dst[j] = src[j];
 }
 
-__global__ __launch_bounds__(256) void lane_stitch_kernel(LaneArgs a)
+// ---- apply: the fixes of a read's chain of units replayed over the input -> the read's staging slot -----------------
+// Which unit's list is the truth up to where follows from the records the units left (lane 0 walks the chain); the
+// lists, concatenated, are the read's fixes in scan order, and the output is the input with them applied (mod.rs:75-102:
+// a fix writes one base and consumes `used` bases of the read; everything else is copied through).  Copying is
+// OUTPUT-centric: every thread produces 16 aligned output bytes, finds the fix its first byte lies behind by bisection
+// of the fixes' output offsets (LDS), and in the common case -- no fix inside its 16 bytes -- moves them as one vector.
+constexpr uint32_t AP_EDITS = 2048; // fixes replayed per batch
+constexpr uint32_t AP_PIECES = 256; // pieces (unit, depth) gathered per batch
+
+__global__ __launch_bounds__(256) void lane_apply_kernel(LaneArgs a)
 {
     const PassParams &p = a.p;
+    __shared__ uint32_t e_raw[AP_EDITS];     // the fixes of the batch
+    __shared__ uint32_t e_os[AP_EDITS + 1];  // output offset (inside the batch) of the copied stretch in front of fix m
+    __shared__ uint32_t e_in[AP_EDITS];      // input position where that stretch starts
+    __shared__ uint64_t pc_src[AP_PIECES];   // pieces: where their fixes are (list index << 60 | entry)
+    __shared__ uint32_t pc_off[AP_PIECES + 1]; // ... and how many came before
+    __shared__ uint32_t sh_part[256];
+    __shared__ uint32_t sh_np, sh_next_u, sh_state;
     for (uint32_t r = blockIdx.x; r < p.n_reads; r += gridDim.x) {
         if (p.in_staged && p.in_lens[r] == 0xffffffffu) { // given up by an earlier pass of this attempt: stays poisoned
             if (threadIdx.x == 0)
                 p.out_lens[r] = 0xffffffffu;
             continue;
         }
+        const uint8_t *in;
+        uint32_t n;
+        bool poisoned;
+        const uint64_t in_at = read_view(p, r, in, n, poisoned);
         const uint64_t o0 = p.offsets[r], o1 = p.offsets[r + 1];
         const uint64_t s0 = slot_of(o0, r, p.slack), s1 = slot_of(o1, (uint64_t)r + 1, p.slack);
         uint8_t *dst = p.out + s0;
         const uint64_t slot = s1 - s0;
-        const uint64_t ub = a.ubase[r], xb = a.xbase[r];
-        uint64_t total = 0;
-        bool failed = false;
-        // every thread walks the chain (uniform loads), all of them copy each piece
-        for (uint64_t u = ub;;) {
-            const uint4 res = *reinterpret_cast<const uint4 *>(a.u_res + 4ull * u);
-            const uint32_t q = a.u_q[u];
-            if (res.w == C_VOID) { // cannot be on the chain
-                failed = true;
-                break;
+        const uint32_t ub = (uint32_t)a.ubase[r];
+        uint64_t total = 0;  // output bytes so far (uniform)
+        uint32_t cur_in = 0; // input bases consumed so far (uniform)
+        bool failed = false, more = true;
+        uint32_t u_next = ub, d_next = 0; // where the chain walk goes on (uniform)
+        while (more && !failed) {
+            // ---- gather pieces until the batch is full (lane 0; the others wait) ----------------------------------------
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                uint32_t np = 0, cnt = 0, u = u_next, d = d_next, state = 1; // state: 0 chain done, 1 more to come, 2 failed
+                pc_off[0] = 0;
+                for (;;) {
+                    const uint4 ra = *reinterpret_cast<const uint4 *>(a.u_res + 8ull * u);
+                    const uint4 rb = *reinterpret_cast<const uint4 *>(a.u_res + 8ull * u + 4);
+                    const uint32_t res[8] = {ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z, rb.w};
+                    const uint32_t code = res[6];
+                    if (code >= (uint32_t)MAX_DEPTH) { // FAIL, or a void unit on the chain (cannot be)
+                        state = 2;
+                        break;
+                    }
+                    bool full = false;
+                    for (; d <= code; d++) {
+                        const uint32_t ne = res[2 * d];
+                        if (np == AP_PIECES || (cnt + ne > AP_EDITS && cnt != 0u)) {
+                            full = true;
+                            break;
+                        }
+                        const uint32_t xu = d == 0 ? u : res[2 * d - 1];
+                        pc_src[np] = ((uint64_t)d << 60) | edit_start(in_at, r, ub, xu - ub, a.u_q[xu]);
+                        cnt += ne; // (a single piece may hold more than a batch: it is then replayed in several)
+                        np++;
+                        pc_off[np] = cnt;
+                    }
+                    if (full)
+                        break;
+                    const uint32_t next = res[2 * code + 1];
+                    if (next == U_END) {
+                        state = 0;
+                        break;
+                    }
+                    u = next;
+                    d = 0;
+                }
+                sh_np = np;
+                sh_next_u = u;
+                sh_state = state | (d << 8);
             }
-            const uint8_t *src = a.X + lane_region(xb, (uint32_t)(u - ub), q, p.slack);
-            if (total + res.x + 1u <= slot)
-                copy_bytes(dst + total, src, res.x);
-            total += res.x;
-            if (res.w == C_FAIL) {
-                failed = true;
+            __syncthreads();
+            const uint32_t np = sh_np;
+            u_next = sh_next_u;
+            d_next = sh_state >> 8;
+            failed = (sh_state & 0xffu) == 2u;
+            more = (sh_state & 0xffu) == 1u;
+            if (failed)
                 break;
+            const uint32_t n_all = pc_off[np];
+            // ---- replay the gathered fixes, AP_EDITS at a time ---------------------------------------------------------
+            for (uint32_t f0 = 0; f0 < n_all; f0 += AP_EDITS) {
+                const uint32_t nb = n_all - f0 < AP_EDITS ? n_all - f0 : AP_EDITS;
+                __syncthreads();
+                for (uint32_t t = threadIdx.x; t < nb; t += 256) {
+                    const uint32_t f = f0 + t;
+                    uint32_t lo = 0, hi = np; // the piece of fix f: pc_off[lo] <= f < pc_off[lo + 1]
+                    while (hi - lo > 1u) {
+                        const uint32_t mid = (lo + hi) >> 1;
+                        if (pc_off[mid] <= f)
+                            lo = mid;
+                        else
+                            hi = mid;
+                    }
+                    const uint64_t src = pc_src[lo];
+                    e_raw[t] = a.E[src >> 60][(src & 0x0fffffffffffffffull) + (f - pc_off[lo])];
+                }
+                __syncthreads();
+                // stretch in front of fix t: from the end of the fix before (cur_in for the first) to its position
+                const uint32_t per = (nb + 255u) / 256u; // consecutive fixes per thread
+                const uint32_t t0 = threadIdx.x * per, t1 = t0 + per < nb ? t0 + per : nb;
+                uint32_t part = 0;
+                for (uint32_t t = t0; t < t1; t++) {
+                    const uint32_t e = e_raw[t];
+                    const uint32_t prev_end = t == 0 ? cur_in : (e_raw[t - 1] >> 4) + ((e_raw[t - 1] >> 2) & 3u);
+                    e_in[t] = prev_end;
+                    part += ((e >> 4) - prev_end) + 1u;
+                }
+                sh_part[threadIdx.x] = part;
+                __syncthreads();
+                for (int o = 1; o < 256; o <<= 1) { // inclusive scan of the 256 partial sums
+                    const uint32_t v = threadIdx.x >= (uint32_t)o ? sh_part[threadIdx.x - o] : 0u;
+                    __syncthreads();
+                    sh_part[threadIdx.x] += v;
+                    __syncthreads();
+                }
+                uint32_t run = sh_part[threadIdx.x] - part;
+                for (uint32_t t = t0; t < t1; t++) {
+                    e_os[t] = run;
+                    run += ((e_raw[t] >> 4) - e_in[t]) + 1u;
+                }
+                const uint32_t batch_total = sh_part[255];
+                if (threadIdx.x == 0)
+                    e_os[nb] = batch_total;
+                __syncthreads();
+                // output bytes [total, total + batch_total), 16 per thread, aligned to the destination
+                if (total + batch_total <= slot) {
+                    uint8_t *ob = dst + total;
+                    const uint32_t head = (uint32_t)((16u - (uint32_t)((uintptr_t)ob & 15u)) & 15u);
+                    const uint32_t n_chunks = (batch_total + (16u - head) % 16u + 15u) / 16u + 1u;
+                    for (uint32_t ch = threadIdx.x; ch < n_chunks; ch += 256) {
+                        // chunk 0 = the bytes in front of the first 16-byte boundary
+                        const uint32_t x0 = ch == 0 ? 0u : head + 16u * (ch - 1u);
+                        uint32_t x1 = ch == 0 ? head : x0 + 16u;
+                        if (x1 > batch_total)
+                            x1 = batch_total;
+                        if (x0 >= x1)
+                            continue;
+                        uint32_t lo = 0, hi = nb; // the fix whose stretch holds byte x0: e_os[lo] <= x0 < e_os[lo + 1]
+                        while (hi - lo > 1u) {
+                            const uint32_t mid = (lo + hi) >> 1;
+                            if (e_os[mid] <= x0)
+                                lo = mid;
+                            else
+                                hi = mid;
+                        }
+                        uint32_t m = lo;
+                        const uint32_t copied_end = e_os[m + 1] - 1u; // the fix's own base sits here
+                        if (x1 - x0 == 16u && x1 <= copied_end) {
+                            uint4 q;
+                            __builtin_memcpy(&q, in + e_in[m] + (x0 - e_os[m]), 16);
+                            *reinterpret_cast<uint4 *>(ob + x0) = q;
+                        } else {
+                            for (uint32_t x = x0; x < x1; x++) {
+                                while (x >= e_os[m + 1])
+                                    m++;
+                                const uint32_t rel = x - e_os[m];
+                                ob[x] = x + 1u == e_os[m + 1] ? bit2nuc(e_raw[m] & 3u) : in[e_in[m] + rel];
+                            }
+                        }
+                    }
+                }
+                total += batch_total;
+                cur_in = (e_raw[nb - 1] >> 4) + ((e_raw[nb - 1] >> 2) & 3u);
             }
-            uint32_t next;
-            if (res.w == C_MATCH1) {
-                next = res.z;
-            } else { // missed its first target t1 = res.z, went on into Y and matched at res.w
-                const uint8_t *src2 = a.Y + lane_region(xb, res.z - (uint32_t)ub, a.u_q[res.z], p.slack);
-                if (total + res.y + 1u <= slot)
-                    copy_bytes(dst + total, src2, res.y);
-                total += res.y;
-                next = res.w;
-            }
-            if (next == U_END)
-                break;
-            u = next;
+        }
+        // the bases behind the last fix
+        if (!failed && n > cur_in) {
+            const uint32_t len = n - cur_in;
+            if (total + len <= slot)
+                copy_bytes(dst + total, in + cur_in, len);
+            total += len;
         }
         if (threadIdx.x == 0) {
             if (failed) {
@@ -607,10 +782,10 @@ __global__ __launch_bounds__(256) void lane_stitch_kernel(LaneArgs a)
 }
 
 struct LaneWork {
-    uint32_t *nu = nullptr, *xsz = nullptr, *u_read = nullptr, *u_q = nullptr, *u_res = nullptr, *fail_list = nullptr;
-    uint64_t *ubase = nullptr, *xbase = nullptr, *u_qk = nullptr;
-    uint8_t *X = nullptr, *Y = nullptr;
-    uint64_t reads_cap = 0, units_cap = 0, x_cap = 0;
+    uint32_t *nu = nullptr, *u_read = nullptr, *u_q = nullptr, *u_res = nullptr, *fail_list = nullptr, *P = nullptr;
+    uint32_t *E[MAX_DEPTH] = {nullptr, nullptr, nullptr};
+    uint64_t *ubase = nullptr, *u_qk = nullptr;
+    uint64_t reads_cap = 0, units_cap = 0, p_cap = 0, e_cap = 0;
 };
 
 int grow_dev(void **ptr, uint64_t bytes)
@@ -652,8 +827,8 @@ void lane_ws_free(brx_chain *ch)
     LaneWork *w = (LaneWork *)ch->lane_ws;
     if (!w)
         return;
-    for (void *q : {(void *)w->nu, (void *)w->xsz, (void *)w->u_read, (void *)w->u_q, (void *)w->u_res, (void *)w->fail_list,
-                    (void *)w->ubase, (void *)w->xbase, (void *)w->u_qk, (void *)w->X, (void *)w->Y})
+    for (void *q : {(void *)w->nu, (void *)w->u_read, (void *)w->u_q, (void *)w->u_res, (void *)w->fail_list, (void *)w->P,
+                    (void *)w->E[0], (void *)w->E[1], (void *)w->E[2], (void *)w->ubase, (void *)w->u_qk})
         if (q)
             (void)hipFree(q);
     delete w;
@@ -662,8 +837,8 @@ void lane_ws_free(brx_chain *ch)
 
 int lane_pass(brx_chain *ch, const PassParams &p, const LanePassInfo &info, hipStream_t s)
 {
-    // BRX_LANE=0: the group kernel only.  The window of a round holds 8 bases: look-aheads up to off + c + 1 <= 8.
-    if (env_u32("BRX_LANE", 1u) == 0u || p.flip || p.c > 5 || p.k > 32 || p.n_reads == 0)
+    // BRX_LANE=0: the group kernel only.  The window of a round shows 8 bases: look-aheads up to off + c + 1 <= 8.
+    if (env_u32("BRX_LANE", 1u) == 0u || p.flip || p.c < 1 || p.c > 5 || p.k > 31 || p.n_reads == 0)
         return BRX_ERR_UNSUPPORTED;
     const bool idx = p.idx.lines != nullptr;
     if (!idx && !p.bits)
@@ -690,16 +865,15 @@ int lane_pass(brx_chain *ch, const PassParams &p, const LanePassInfo &info, hipS
         ch->lane_ws = w;
     }
     const uint64_t units_bound = info.in_total_bound / C + (uint64_t)p.n_reads + 1ull;
-    const uint64_t x_bound = info.in_total_bound + (info.in_total_bound >> 2) * p.slack + 64ull * (units_bound + p.n_reads) + 256ull;
     if (units_bound >= 0xfffffff0ull)
         return BRX_ERR_UNSUPPORTED;
+    const uint64_t p_bound = (info.in_total_bound >> 4) + 5ull * p.n_reads + 16ull;                        // dwords
+    const uint64_t e_bound = (info.in_total_bound >> 2) + 16ull * (units_bound + 2ull * p.n_reads) + 64ull; // entries
     if (w->reads_cap < p.n_reads) {
         const uint64_t cap = (uint64_t)p.n_reads + p.n_reads / 8 + 64;
         BRX_TRY(grow_dev((void **)&w->nu, cap * 4));
-        BRX_TRY(grow_dev((void **)&w->xsz, cap * 4));
         BRX_TRY(grow_dev((void **)&w->fail_list, cap * 4));
         BRX_TRY(grow_dev((void **)&w->ubase, (cap + 1) * 8));
-        BRX_TRY(grow_dev((void **)&w->xbase, (cap + 1) * 8));
         w->reads_cap = cap;
     }
     if (w->units_cap < units_bound) {
@@ -707,36 +881,37 @@ int lane_pass(brx_chain *ch, const PassParams &p, const LanePassInfo &info, hipS
         BRX_TRY(grow_dev((void **)&w->u_read, cap * 4));
         BRX_TRY(grow_dev((void **)&w->u_q, cap * 4));
         BRX_TRY(grow_dev((void **)&w->u_qk, cap * 8));
-        BRX_TRY(grow_dev((void **)&w->u_res, cap * 16));
+        BRX_TRY(grow_dev((void **)&w->u_res, cap * 32));
         w->units_cap = cap;
     }
-    if (w->x_cap < x_bound) {
-        const uint64_t cap = x_bound + x_bound / 16;
-        BRX_TRY(grow_dev((void **)&w->X, cap));
-        BRX_TRY(grow_dev((void **)&w->Y, cap));
-        w->x_cap = cap;
+    if (w->p_cap < p_bound) {
+        const uint64_t cap = p_bound + p_bound / 16;
+        BRX_TRY(grow_dev((void **)&w->P, cap * 4));
+        w->p_cap = cap;
     }
-    {
-        uint64_t tmp_bytes = ch->scan_tmp_cap;
-        if (scan_tmp_bytes(p.n_reads) > tmp_bytes) {
-            set_error("lane pass: scan scratch smaller than the batch");
-            return BRX_ERR_ARG;
-        }
+    if (w->e_cap < e_bound) {
+        const uint64_t cap = e_bound + e_bound / 16;
+        for (int d = 0; d < MAX_DEPTH; d++)
+            BRX_TRY(grow_dev((void **)&w->E[d], cap * 4));
+        w->e_cap = cap;
+    }
+    if (scan_tmp_bytes(p.n_reads) > ch->scan_tmp_cap) {
+        set_error("lane pass: scan scratch smaller than the batch");
+        return BRX_ERR_ARG;
     }
     LaneArgs a;
     a.p = p;
     a.C = C;
     a.R = R;
     a.nu = w->nu;
-    a.xsz = w->xsz;
     a.ubase = w->ubase;
-    a.xbase = w->xbase;
     a.u_read = w->u_read;
     a.u_q = w->u_q;
     a.u_qk = w->u_qk;
     a.u_res = w->u_res;
-    a.X = w->X;
-    a.Y = w->Y;
+    a.P = w->P;
+    for (int d = 0; d < MAX_DEPTH; d++)
+        a.E[d] = w->E[d];
     a.fail_list = w->fail_list;
 
     const uint32_t rb = (p.n_reads + 255u) / 256u;
@@ -745,8 +920,8 @@ int lane_pass(brx_chain *ch, const PassParams &p, const LanePassInfo &info, hipS
         BRX_HIP(hipMemsetAsync(p.ctrl + CTL_LANE_UNITS, 0, (CTL_N - CTL_LANE_UNITS) * 8, s));
         lane_units_kernel<<<rb, 256, 0, s>>>(a);
         BRX_TRY(exclusive_scan_lens(w->nu, p.n_reads, ch->d_scan_tmp, w->ubase, p.ctrl + CTL_LANE_UNITS, s));
-        BRX_TRY(exclusive_scan_lens(w->xsz, p.n_reads, ch->d_scan_tmp, w->xbase, p.ctrl + CTL_LANE_XBYTES, s));
-        lane_fill_kernel<<<rb, 256, 0, s>>>(a);
+        const uint32_t grid = p.n_reads < (1u << 16) ? p.n_reads : (1u << 16);
+        lane_pack_kernel<<<grid, 256, 0, s>>>(a);
     }
     {
         KernelTimer t("lane_sync", s);
@@ -767,12 +942,12 @@ int lane_pass(brx_chain *ch, const PassParams &p, const LanePassInfo &info, hipS
             launch_lane<false>(a, blocks, s);
     }
     {
-        KernelTimer t("lane_stitch", s);
+        KernelTimer t("lane_apply", s);
         const uint32_t grid = p.n_reads < (1u << 16) ? p.n_reads : (1u << 16);
-        lane_stitch_kernel<<<grid, 256, 0, s>>>(a);
+        lane_apply_kernel<<<grid, 256, 0, s>>>(a);
     }
     {
-        // the reads the units could not settle (two misses in a row, a stretch that outgrew its region): the group kernel
+        // the reads the units could not settle (three misses in a row, more fixes than a list holds): the group kernel
         KernelTimer t("lane_redo", s);
         PassParams q = p;
         q.only = w->fail_list;

@@ -25,7 +25,7 @@ line = [l for l in open(out + "/a.log") if l.startswith("{")]
 stats = json.loads(line[-1])["correct_stats"] if line else {}
 res = {"correct_stats": stats}
 for name, c in agg.items():
-    if "correct_kernel" not in name and "one_kernel" not in name and "one_lane_kernel" not in name:
+    if not any(t in name for t in ("correct_kernel", "one_kernel", "lane_")):
         continue
     d = {k: sum(v) / len(v) for k, v in c.items()}
     ms = sum(dur[name]) / max(len(dur[name]), 1)
