@@ -54,7 +54,9 @@ constexpr uint32_t C_FAIL = 0xfffffff1u;   // res[6]: three misses in a row, or 
 constexpr uint32_t C_VOID = 0xfffffff2u;   // res[6]: nothing produced
 constexpr int MAX_DEPTH = 3;               // edit lists: own stretch + two stretches scanned after a miss
 constexpr uint32_t MAX_LANE_READ = 1u << 28; // positions are kept in 28 bits of an edit
+constexpr uint32_t LANE_GRAB = 64;           // units a wave draws from the global counter at a time
 
+struct UnitDesc;
 struct LaneArgs {
     PassParams p;
     uint32_t C;                // nominal chunk length
@@ -65,6 +67,7 @@ struct LaneArgs {
     uint32_t *u_q;             // its sync position (0 for a read's first)  [units]
     uint64_t *u_qk;            // the original k-mer in front of it         [units]
     uint32_t *u_res;           // n0 t1 n1 t2 n2 t3 code -                  [8 x units]
+    UnitDesc *u_desc;          // what a lane loads to start on a unit      [units]
     uint32_t *P;               // the batch as 2-bit codes, 16 bases per dword, first base in the top bits
     uint32_t *E[MAX_DEPTH];    // edit lists: pos << 4 | consumed << 2 | base
     uint32_t *fail_list;       // reads handed back to the group kernel     [n_reads]
@@ -226,6 +229,60 @@ __global__ __launch_bounds__(256) void lane_sync_kernel(LaneArgs a)
     }
 }
 
+// Everything a lane needs to start on a unit, or to go on into it after a missed prediction, in ONE 48-byte record: a
+// lane that takes a unit stalls its whole wave while the loads it depends on come back, so the chain is kept at
+// counter -> record -> window (the first form of the hand-out walked ten dependent loads and cost as much as the scan
+// of short units itself).
+struct __attribute__((aligned(16))) UnitDesc {
+    uint32_t n;     // length of the read
+    uint32_t q;     // sync position (0 for a read's first unit; U_VOID: no sync point, nothing to do)
+    uint32_t t1;    // the next unit of the read that has a sync point (U_END: none)
+    uint32_t tgt;   // its sync position (the read's length for U_END)
+    uint64_t tgtk;  // the original k-mer in front of it
+    uint64_t eat;   // first entry of this unit's stretch in an edit list
+    uint64_t pw;    // dword of P that holds position q
+    uint32_t ecap;  // entries up to the target's stretch
+    uint32_t first; // 1: the read's first unit (the scan starts at position k, mod.rs:60-67)
+};
+
+__global__ __launch_bounds__(256) void lane_link_kernel(LaneArgs a)
+{
+    const PassParams &p = a.p;
+    const unsigned long long n_units = p.ctrl[CTL_LANE_UNITS];
+    for (unsigned long long u = (unsigned long long)blockIdx.x * 256ull + threadIdx.x; u < n_units; u += (unsigned long long)gridDim.x * 256ull) {
+        const uint32_t r = a.u_read[u];
+        const uint32_t ub = (uint32_t)a.ubase[r], uend = (uint32_t)a.ubase[r + 1];
+        const uint8_t *in;
+        uint32_t n;
+        bool poisoned;
+        const uint64_t in_at = read_view(p, r, in, n, poisoned);
+        UnitDesc d;
+        d.n = n;
+        d.q = n >= MAX_LANE_READ ? U_VOID - 1u : a.u_q[u]; // (U_VOID - 1: the read is too long for the edits' 28-bit positions)
+        uint32_t t = (uint32_t)u + 1u;
+        while (t < uend && a.u_q[t] == U_VOID)
+            t++;
+        const uint32_t q0 = d.q >= U_VOID - 1u ? 0u : d.q;
+        d.eat = edit_start(in_at, r, ub, (uint32_t)u - ub, q0);
+        uint64_t end_at;
+        if (t < uend) {
+            d.t1 = t;
+            d.tgt = a.u_q[t];
+            d.tgtk = a.u_qk[t];
+            end_at = edit_start(in_at, r, ub, t - ub, d.tgt);
+        } else {
+            d.t1 = U_END;
+            d.tgt = n;
+            d.tgtk = 0;
+            end_at = edit_start(in_at, r, ub, uend - ub, n);
+        }
+        d.ecap = (uint32_t)(end_at - d.eat);
+        d.pw = pack_start(in_at, r) + (q0 >> 4);
+        d.first = (uint32_t)u == ub ? 1u : 0u;
+        a.u_desc[u] = d;
+    }
+}
+
 // ---- the automaton ----------------------------------------------------------------------------------------------------
 // One round of one lane = one KmerSet::get and the transition it decides.  The round is written as straight-line code
 // over a PACKED state word, so that the 64 lanes of a wave -- each in a state of its own -- share every instruction;
@@ -252,7 +309,7 @@ __global__ __launch_bounds__(256, 7) void lane_kernel(LaneArgs a)
 
     // the unit
     bool have = false, want = true;
-    uint32_t u = 0, r = 0, n = 0, i = 0, tgt = 0, t1 = U_END;
+    uint32_t u = 0, n = 0, i = 0, tgt = 0, t1 = U_END;
     uint64_t tgtk = 0;
     uint32_t depth = 0, ne = 0, ecap = 0;
     uint64_t eat = 0; // first entry of the edit list being written
@@ -263,41 +320,15 @@ __global__ __launch_bounds__(256, 7) void lane_kernel(LaneArgs a)
     uint64_t kmer = 0, corr = 0;
     uint32_t S = 0, hop = 0, cline = 0xffffffffu;
     uint32_t n_rounds = 0, n_probes = 0, n_trig = 0, n_fix = 0, n_miss = 0; // wave-uniform (scalar registers)
-
-    // where the edits of unit jj (sync position q) of this lane's read start
-    auto unit_edits = [&](uint32_t jj, uint32_t q) {
-        const uint8_t *in;
-        uint32_t nn;
-        bool poisoned;
-        const uint64_t in_at = read_view(p, r, in, nn, poisoned);
-        return edit_start(in_at, r, a.ubase[r], jj, q);
-    };
-    // the next unit of this read at or after `from` that has a sync point (none: the end of the read) becomes the
-    // target; returns where its edits start = where this stretch's list must end
-    auto set_target = [&](uint32_t from) {
-        const uint32_t ubl = (uint32_t)a.ubase[r], uend = (uint32_t)a.ubase[r + 1];
-        uint32_t t = from;
-        while (t < uend && a.u_q[t] == U_VOID)
-            t++;
-        if (t < uend) {
-            t1 = t;
-            tgt = a.u_q[t];
-            tgtk = a.u_qk[t];
-            return unit_edits(t - ubl, tgt);
-        }
-        t1 = U_END;
-        tgt = n;
-        tgtk = 0;
-        return unit_edits(uend - ubl, n);
-    };
+    uint32_t wnext = 0, wend = 0; // the units this wave has drawn and not yet dealt out (wave-uniform)
 
     for (;;) {
         // ---- rare: a unit ends where the scan reaches its target (loop top, mod.rs:68); units are handed out --------
         uint32_t ev = 0; // this lane's events of the round: 1 probe, 2 trigger, 4 fix, 8 missed prediction
         const bool at_end = have && (S & 3u) == 0u && i >= tgt;
         if (__any(at_end || want)) {
-            uint32_t *res = a.u_res + 8ull * u;
             if (at_end) {
+                uint32_t *res = a.u_res + 8ull * u;
                 res[2 * depth] = ne;
                 res[2 * depth + 1] = t1;
                 if (t1 == U_END || (i == tgt && kmer == tgtk)) {
@@ -307,61 +338,94 @@ __global__ __launch_bounds__(256, 7) void lane_kernel(LaneArgs a)
                     // the prediction did not hold: keep scanning through the next unit's stretch, into the next list
                     ev |= 8u;
                     depth++;
-                    eat = unit_edits(t1 - (uint32_t)a.ubase[r], tgt);
+                    const uint4 *dp = reinterpret_cast<const uint4 *>(a.u_desc + t1);
+                    const uint4 d0 = dp[0], d1 = dp[1], d2 = dp[2];
+                    t1 = d0.z;
+                    tgt = d0.w;
+                    tgtk = ((uint64_t)d1.y << 32) | d1.x;
+                    eat = ((uint64_t)d1.w << 32) | d1.z;
+                    ecap = d2.z;
                     ne = 0;
-                    ecap = (uint32_t)(set_target(t1 + 1u) - eat);
                 } else {
                     res[6] = C_FAIL;
                     want = true;
                 }
             }
-            while (want) { // ONE place where a lane takes a new unit
-                const unsigned long long w = atomicAdd(p.ctrl + CTL_LANE_WORK, 1ull);
-                want = false;
-                have = w < n_units;
-                if (!have)
+            // ONE place where lanes take new units.  The wave draws LANE_GRAB units at a time from the global counter (one
+            // atomic per 64 units: 7 168 waves incrementing one address once per unit measured ~8 ns per unit, i.e. the whole
+            // kernel's time at short chunks) and deals them to its lanes from a wave-uniform cursor.
+            for (;;) {
+                const uint64_t wm = __ballot(want);
+                if (!wm)
                     break;
-                u = (uint32_t)w;
-                res = a.u_res + 8ull * u;
-                r = a.u_read[u];
-                const uint32_t j = u - (uint32_t)a.ubase[r];
-                const uint8_t *in;
-                bool poisoned;
-                const uint64_t in_at = read_view(p, r, in, n, poisoned);
-                const uint32_t q = a.u_q[u];
-                if (q == U_VOID || n >= MAX_LANE_READ) {
-                    res[6] = q == U_VOID ? C_VOID : C_FAIL;
-                    want = true;
-                    continue;
-                }
-                eat = unit_edits(j, q);
-                ecap = (uint32_t)(set_target(u + 1u) - eat);
-                depth = 0;
-                ne = 0;
-                hop = 0;
-                // the window at q
-                const uint64_t pw = pack_start(in_at, r) + (q >> 4);
-                wreg = (((uint64_t)a.P[pw] << 32) | a.P[pw + 1]) << ((q & 15u) * 2u);
-                wcnt = 32u - (q & 15u);
-                nextw = a.P[pw + 2];
-                pidx = (uint32_t)pw + 3u;
-                if (j == 0) {
-                    if (n < (uint32_t)k) { // mod.rs:56-58: returned verbatim, i.e. no edits
-                        res[0] = 0;
-                        res[1] = U_END;
-                        res[6] = 0;
-                        want = true;
-                        continue;
+                if (wnext == wend) {
+                    unsigned long long base = 0;
+                    if ((tid & 63u) == 0u)
+                        base = atomicAdd(p.ctrl + CTL_LANE_WORK, (unsigned long long)LANE_GRAB);
+                    base = __shfl(base, 0);
+                    wnext = base < n_units ? (uint32_t)base : (uint32_t)n_units;
+                    wend = base + LANE_GRAB < n_units ? (uint32_t)(base + LANE_GRAB) : (uint32_t)n_units;
+                    if (wnext == wend) { // the pass has no units left
+                        if (want)
+                            have = false;
+                        want = false;
+                        break;
                     }
-                    kmer = wreg >> (64 - 2 * k);
-                    wreg <<= 2 * k; // k <= 31
-                    wcnt -= (uint32_t)k;
-                    i = (uint32_t)k;
-                    S = 1u << S_FIRST; // previous = get(kmer), mod.rs:67: SCAN that probes kmer itself; prev = false accepts it
-                } else {
-                    i = q;
-                    kmer = a.u_qk[u];
-                    S = 1u << S_PREV; // R >= 1 solid k-mers end in front of q
+                }
+                const uint32_t rank = (uint32_t)__builtin_popcountll(wm & ((1ull << (tid & 63u)) - 1ull));
+                const uint32_t avail = wend - wnext;
+                const uint32_t asked = (uint32_t)__builtin_popcountll(wm);
+                const bool take = want && rank < avail;
+                const uint32_t my = wnext + rank;
+                wnext += asked < avail ? asked : avail;
+                if (take) {
+                    want = false;
+                    have = true;
+                    u = my;
+                    const uint4 *dp = reinterpret_cast<const uint4 *>(a.u_desc + u);
+                    const uint4 d0 = dp[0], d1 = dp[1], d2 = dp[2];
+                    n = d0.x;
+                    const uint32_t q = d0.y;
+                    if (q >= U_VOID - 1u) {
+                        a.u_res[8ull * u + 6] = q == U_VOID ? C_VOID : C_FAIL;
+                        have = false;
+                        want = true;
+                    } else {
+                        t1 = d0.z;
+                        tgt = d0.w;
+                        tgtk = ((uint64_t)d1.y << 32) | d1.x;
+                        eat = ((uint64_t)d1.w << 32) | d1.z;
+                        const uint64_t pw = ((uint64_t)d2.y << 32) | d2.x;
+                        ecap = d2.z;
+                        depth = 0;
+                        ne = 0;
+                        hop = 0;
+                        // the window at q
+                        wreg = (((uint64_t)a.P[pw] << 32) | a.P[pw + 1]) << ((q & 15u) * 2u);
+                        wcnt = 32u - (q & 15u);
+                        nextw = a.P[pw + 2];
+                        pidx = (uint32_t)pw + 3u;
+                        if (d2.w) { // the read's first unit
+                            if (n < (uint32_t)k) { // mod.rs:56-58: returned verbatim, i.e. no edits
+                                uint32_t *res = a.u_res + 8ull * u;
+                                res[0] = 0;
+                                res[1] = U_END;
+                                res[6] = 0;
+                                have = false;
+                                want = true;
+                            } else {
+                                kmer = wreg >> (64 - 2 * k);
+                                wreg <<= 2 * k; // k <= 31
+                                wcnt -= (uint32_t)k;
+                                i = (uint32_t)k;
+                                S = 1u << S_FIRST; // previous = get(kmer), mod.rs:67: SCAN that probes kmer itself; prev = false accepts it
+                            }
+                        } else {
+                            i = q;
+                            kmer = a.u_qk[u];
+                            S = 1u << S_PREV; // R >= 1 solid k-mers end in front of q
+                        }
+                    }
                 }
             }
             if (!__any(have))
@@ -381,34 +445,38 @@ __global__ __launch_bounds__(256, 7) void lane_kernel(LaneArgs a)
             const uint32_t c0 = cw >> 14;               // seq[i]
             const uint32_t st = S & 3u, cur = (S >> S_CUR) & 3u, jj = (S >> S_JJ) & 7u, skip = (S >> S_SKIP) & 7u;
             const bool prev = (S >> S_PREV) & 1u, first = (S >> S_FIRST) & 1u, slow = (S >> S_SLOW) & 1u;
+            const bool is0 = st == 0u, is1 = st == 1u, is2 = st == 2u, is3 = st == 3u;
             const uint32_t rem = n - i;
 
             // ---- the k-mer this state asks about ------------------------------------------------------------------------
             const uint32_t off = 2u - cur; // I:2 S:1 D:0 (one.rs:57-63); meaningful in SCEN / MORE only
-            const uint32_t nb = st == 0u ? (first ? 0u : 1u) : (st == 2u ? jj + 1u : (st == 3u ? c + 1u : 0u));
-            const uint32_t b0 = st >= 2u ? off : 0u;
+            const uint32_t nb = is0 ? (first ? 0u : 1u) : (is2 ? jj + 1u : (is3 ? c + 1u : 0u));
+            const uint32_t b0 = (is2 || is3) ? off : 0u;
             const uint32_t wbits = (cw >> (16u - 2u * (b0 + nb))) & ((1u << (2u * nb)) - 1u);
-            uint64_t pk = (((st == 0u ? kmer : corr) << (2u * nb)) | (uint64_t)wbits) & mask;
-            if (st == 1u)
-                pk = (pk & ~3ull) | (uint64_t)cur;
+            uint64_t pk = (((is0 ? kmer : corr) << (2u * nb)) | (uint64_t)wbits) & mask;
+            pk = is1 ? ((pk & ~3ull) | (uint64_t)cur) : pk;
             // a base accepted behind a fix is known solid (it was a look-ahead of the winning scenario); a tie-break
             // that cannot read one base more is false without a probe (exist/mod.rs:54)
-            const bool need = !(st == 0u && skip != 0u) && !(st == 3u && !(rem > c + off + 1u));
+            const bool need = !(is0 && skip != 0u) && !(is3 && !(rem > c + off + 1u));
             ev |= need ? 1u : 0u;
 
             // ---- KmerSet::get -------------------------------------------------------------------------------------------
-            bool sol = (st == 0u) && !need, unres = false;
+            bool sol = is0 && !need, unres = false;
             if (IDX) {
                 uint64_t key;
                 const uint32_t home = index_locate(p.idx, pk, k, key);
                 const uint32_t line = (home + hop) & (0xffffffffu >> p.idx.line_shift);
                 if (need && !slow && line != cline) { // not the line this lane holds: fetch it, keep it
-                    const uint4 *L = reinterpret_cast<const uint4 *>(p.idx.lines + (uint64_t)line * 8ull);
-                    const uint4 q0 = L[0], q1 = L[1], q2 = L[2], q3 = L[3];
-                    lc[0][tid] = q0;
-                    lc[1][tid] = q1;
-                    lc[2][tid] = q2;
-                    lc[3][tid] = q3;
+                    // straight from global memory into LDS (global_load_lds_dwordx4: lane l of the wave writes at the
+                    // wave-uniform base + 16 l, lanes switched off write nothing: tools/lds_dma_test.hip): no registers
+                    // in between, no ds_write
+                    const uint8_t *L = reinterpret_cast<const uint8_t *>(p.idx.lines + (uint64_t)line * 8ull);
+                    const uint32_t wb = tid & ~63u;
+#pragma unroll
+                    for (int e = 0; e < 4; e++)
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(L + 16 * e),
+                                                         (__attribute__((address_space(3))) void *)&lc[e][wb], 16, 0, 0);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     cline = line;
                 }
                 if (need && slow) { // the home line overflowed at build time and does not hold the key: the bit vector knows
@@ -438,108 +506,69 @@ __global__ __launch_bounds__(256, 7) void lane_kernel(LaneArgs a)
                     hop++;
             } else {
                 hop = 0;
-                // ---- transition ---------------------------------------------------------------------------------------------
-                uint32_t T = S & ~(1u << S_SLOW);
-                bool fail = false;
-                int apply = -1;
-                uint32_t adv = 0;
-                if (st == 0u) {
-                    if (sol || !prev) { // mod.rs:99-102 (and mod.rs:67 for `first`)
-                        adv = first ? 0u : 1u;
-                        kmer = pk;
-                        T = (T & ~((1u << S_PREV) | (1u << S_FIRST) | (7u << S_SKIP))) | ((sol ? 1u : 0u) << S_PREV) |
-                            ((skip ? skip - 1u : 0u) << S_SKIP);
-                    } else { // mod.rs:73: the first k-mer that is not solid after a solid one
-                        corr = pk;
-                        // am = 0; the read's own base IS the trigger k-mer, known not solid: start at the other end
-                        T = (T & ~((15u << S_AM) | (3u << S_CUR) | 3u)) | 1u | ((c0 == 0u ? 1u : 0u) << S_CUR);
-                        ev |= 2u;
-                    }
-                } else if (st == 1u) {
-                    const uint32_t am = ((T >> S_AM) & 15u) | ((sol ? 1u : 0u) << cur);
-                    uint32_t an = cur + 1u;
-                    an += (an == c0) ? 1u : 0u;
-                    T = (T & ~((15u << S_AM) | (3u << S_CUR))) | (am << S_AM) | ((an & 3u) << S_CUR);
-                    if (an >= 4u || __popc(am) > 1) {
-                        if (__popc(am) == 1) { // exist/mod.rs:121-129
-                            corr = (corr & ~3ull) | (uint64_t)(__ffs(am) - 1);
-                            // scenarios that cannot read their c look-aheads (exist/mod.rs:27-29): I needs c+2, S c+1, D c
-                            const uint32_t failm = rem >= c + 2u ? 0u : (rem == c + 1u ? 1u : (rem == c ? 3u : 7u));
-                            if (failm == 7u) {
-                                fail = true;
-                            } else {
-                                const uint32_t s0 = (uint32_t)__ffs(7u & ~failm) - 1u;
-                                T = (T & ~((7u << S_FAILM) | (7u << S_PASS) | (7u << S_JJ) | (3u << S_CUR) | 3u)) | 2u | (s0 << S_CUR) |
-                                    (failm << S_FAILM);
-                            }
-                        } else {
-                            fail = true; // exist/mod.rs:123-126
-                        }
-                    }
-                } else if (st == 2u) {
-                    uint32_t passm = (T >> S_PASS) & 7u, failm = (T >> S_FAILM) & 7u;
-                    bool over = !sol;
-                    if (sol) {
-                        if (jj + 1u == c) { // get_score == c
-                            passm |= 1u << cur;
-                            over = true;
-                        }
-                    } else { // exist/mod.rs:38-42: the score stops below c
-                        failm |= 1u << cur;
-                    }
-                    T = (T & ~((7u << S_PASS) | (7u << S_FAILM) | (7u << S_JJ))) | (passm << S_PASS) | (failm << S_FAILM) |
-                        ((over ? 0u : jj + 1u) << S_JJ);
-                    if (over) {
-                        const uint32_t rest = 7u & ~failm & ~passm & ~((2u << cur) - 1u);
-                        if (rest) {
-                            T = (T & ~(3u << S_CUR)) | (((uint32_t)__ffs(rest) - 1u) << S_CUR);
-                        } else if (passm == 0u) {
-                            fail = true; // exist/mod.rs:132-134
-                        } else if (__popc(passm) == 1) {
-                            apply = __ffs(passm) - 1; // exist/mod.rs:135-137
-                        } else { // several scenarios scored c: one base more decides (exist/mod.rs:138-147)
-                            T = (T & ~((7u << S_KEEP) | (3u << S_CUR) | 3u)) | 3u | (((uint32_t)__ffs(passm) - 1u) << S_CUR);
-                        }
-                    }
-                } else {
-                    const uint32_t passm = (T >> S_PASS) & 7u;
-                    const uint32_t keep = ((T >> S_KEEP) & 7u) | ((sol ? 1u : 0u) << cur);
-                    T = (T & ~(7u << S_KEEP)) | (keep << S_KEEP);
-                    const uint32_t rest = passm & ~((2u << cur) - 1u);
-                    if (rest)
-                        T = (T & ~(3u << S_CUR)) | (((uint32_t)__ffs(rest) - 1u) << S_CUR);
-                    else if (__popc(keep) == 1)
-                        apply = __ffs(keep) - 1;
-                    else
-                        fail = true;
-                }
-                if (fail) { // mod.rs:91-96: the trigger base is copied through, the k-mer keeps it; previous = false
-                    adv = 1;
-                    kmer = (corr & ~3ull) | (uint64_t)c0;
-                    T &= ~((1u << S_PREV) | 3u);
-                }
-                if (apply >= 0) { // mod.rs:75-89 with one.rs:65-71: one base out, `used` bases of the read consumed
-                    const uint32_t used = 2u - (uint32_t)apply;
-                    if (ne < ecap) {
+                // ---- transition: every state's successor computed side by side, one select per field ------------------------
+                const uint32_t solb = sol ? 1u : 0u, bit = 1u << cur, above = ~((2u << cur) - 1u);
+                const uint32_t am = (S >> S_AM) & 15u, passm = (S >> S_PASS) & 7u, failm = (S >> S_FAILM) & 7u, keep = (S >> S_KEEP) & 7u;
+                // SCAN (mod.rs:73, 99-102; mod.rs:67 for `first`)
+                const bool accept = is0 && (sol || !prev), trig = is0 && !accept;
+                // ALTS (mod.rs:114-128, exist/mod.rs:121-129): the read's own base is the trigger k-mer, known not solid
+                const uint32_t am1 = am | (solb << cur);
+                uint32_t an = cur + 1u;
+                an += (an == c0) ? 1u : 0u;
+                const bool alts_end = is1 && (an >= 4u || __popc(am1) > 1);
+                // scenarios that cannot read their c look-aheads (exist/mod.rs:27-29): I needs c + 2 bases, S c + 1, D c
+                const uint32_t failm0 = rem >= c + 2u ? 0u : (rem == c + 1u ? 1u : (rem == c ? 3u : 7u));
+                const bool to_scen = alts_end && __popc(am1) == 1 && failm0 != 7u;
+                // SCEN (exist/mod.rs:21-47, :97-109): the score of scenario cur stops at the first k-mer that is not solid
+                const bool s_pass = is2 && sol && jj + 1u == c, s_over = is2 && (!sol || s_pass);
+                const uint32_t pass1 = passm | (s_pass ? bit : 0u), fail1 = failm | ((is2 && !sol) ? bit : 0u);
+                const uint32_t rest_s = 7u & ~fail1 & ~pass1 & above;
+                const bool scen_end = s_over && rest_s == 0u;
+                const bool to_more = scen_end && __popc(pass1) > 1; // several scored c: one base more decides (exist/mod.rs:138-147)
+                // MORE
+                const uint32_t keep1 = keep | (is3 ? solb << cur : 0u);
+                const uint32_t rest_m = passm & above;
+                const bool more_end = is3 && rest_m == 0u;
+                // verdicts
+                const bool apply_b = (scen_end && __popc(pass1) == 1) || (more_end && __popc(keep1) == 1);
+                const bool fail = (alts_end && !to_scen) || (scen_end && pass1 == 0u) || (more_end && __popc(keep1) != 1);
+                const uint32_t win = (uint32_t)__ffs(is2 ? pass1 : keep1) - 1u; // the scenario applied (if apply_b)
+                const uint32_t used = 2u - win;                                // bases of the read it consumes (one.rs:65-71)
+                // The c look-ahead k-mers of the winning scenario ARE the next c scan k-mers, all found solid: the reference's
+                // loop copies these bases with previous = true (mod.rs:99-102).  Jump over them -- unless the unit's target
+                // lies among them: then they are walked one by one (without a probe), so that the state at the target is seen
+                const bool jump = tgt - i > used + c;
+                const uint32_t cb = (cw >> (16u - 2u * (used + c))) & ((1u << (2u * c)) - 1u);
+                const bool room = ne < ecap;
+                const bool fix = apply_b && room;
+                // the new state word
+                const uint32_t st1 = trig ? 1u : (to_scen ? 2u : (to_more ? 3u : ((fail || apply_b) ? 0u : st)));
+                uint32_t cur1 = is1 ? (an & 3u) : ((s_over && rest_s) ? (uint32_t)__ffs(rest_s) - 1u : ((is3 && rest_m) ? (uint32_t)__ffs(rest_m) - 1u : cur));
+                cur1 = trig ? (c0 == 0u ? 1u : 0u) : (to_scen ? (uint32_t)__ffs(7u & ~failm0) - 1u : (to_more ? (uint32_t)__ffs(pass1) - 1u : cur1));
+                const uint32_t jj1 = (is2 && !s_over) ? jj + 1u : 0u;
+                const uint32_t amn = trig ? 0u : (is1 ? am1 : am);
+                const uint32_t passn = to_scen ? 0u : pass1, failn = to_scen ? failm0 : fail1, keepn = to_more ? 0u : keep1;
+                const uint32_t skipn = accept ? (skip ? skip - 1u : 0u) : ((fix && !jump) ? c : skip);
+                const uint32_t prevn = accept ? solb : (fail ? 0u : (apply_b ? 1u : (prev ? 1u : 0u)));
+                S = st1 | (cur1 << S_CUR) | (jj1 << S_JJ) | (amn << S_AM) | (passn << S_PASS) | (failn << S_FAILM) | (keepn << S_KEEP) |
+                    (skipn << S_SKIP) | (prevn << S_PREV);
+                // the k-mers: a failed fix copies the trigger base through and keeps it in the k-mer (mod.rs:91-96)
+                const uint64_t corr_alt = (corr & ~3ull) | (uint64_t)((uint32_t)__ffs(am1) - 1u);
+                const uint64_t kfix = jump ? (((corr << (2u * c)) | (uint64_t)cb) & mask) : corr;
+                kmer = accept ? pk : (fail ? ((corr & ~3ull) | (uint64_t)c0) : (fix ? kfix : kmer));
+                corr = trig ? pk : (to_scen ? corr_alt : corr);
+                const uint32_t adv = accept ? (first ? 0u : 1u) : (fail ? 1u : (fix ? used + (jump ? c : 0u) : 0u));
+                ev |= (trig ? 2u : 0u) | (fix ? 4u : 0u);
+                if (apply_b) { // mod.rs:75-89: one base out, `used` bases of the read consumed -- the lane's only output
+                    if (room) {
                         a.E[depth][eat + ne] = (i << 4) | (used << 2) | (uint32_t)(corr & 3ull);
                         ne++;
-                        ev |= 4u;
-                        // The c look-ahead k-mers of the winning scenario ARE the next c scan k-mers, all found solid: the
-                        // reference's loop copies these bases with previous = true (mod.rs:99-102).  Jump over them -- unless
-                        // the unit's target lies among them: then they are walked one by one (without a probe), so that the
-                        // state at the target is seen
-                        const bool jump = tgt - i > used + c;
-                        const uint32_t cb = (cw >> (16u - 2u * (used + c))) & ((1u << (2u * c)) - 1u);
-                        kmer = jump ? (((corr << (2u * c)) | (uint64_t)cb) & mask) : corr;
-                        adv = used + (jump ? c : 0u);
-                        T = (T & ~((7u << S_SKIP) | 3u)) | (1u << S_PREV) | ((jump ? 0u : c) << S_SKIP);
                     } else { // more fixes than the list holds: the read goes back to the group kernel
                         a.u_res[8ull * u + 6] = C_FAIL;
                         have = false;
                         want = true;
                     }
                 }
-                S = T;
                 i += adv;
                 wreg <<= 2u * adv;
                 wcnt -= adv;
@@ -783,6 +812,7 @@ __global__ __launch_bounds__(256) void lane_apply_kernel(LaneArgs a)
 
 struct LaneWork {
     uint32_t *nu = nullptr, *u_read = nullptr, *u_q = nullptr, *u_res = nullptr, *fail_list = nullptr, *P = nullptr;
+    UnitDesc *u_desc = nullptr;
     uint32_t *E[MAX_DEPTH] = {nullptr, nullptr, nullptr};
     uint64_t *ubase = nullptr, *u_qk = nullptr;
     uint64_t reads_cap = 0, units_cap = 0, p_cap = 0, e_cap = 0;
@@ -827,7 +857,7 @@ void lane_ws_free(brx_chain *ch)
     LaneWork *w = (LaneWork *)ch->lane_ws;
     if (!w)
         return;
-    for (void *q : {(void *)w->nu, (void *)w->u_read, (void *)w->u_q, (void *)w->u_res, (void *)w->fail_list, (void *)w->P,
+    for (void *q : {(void *)w->u_desc, (void *)w->nu, (void *)w->u_read, (void *)w->u_q, (void *)w->u_res, (void *)w->fail_list, (void *)w->P,
                     (void *)w->E[0], (void *)w->E[1], (void *)w->E[2], (void *)w->ubase, (void *)w->u_qk})
         if (q)
             (void)hipFree(q);
@@ -882,6 +912,7 @@ int lane_pass(brx_chain *ch, const PassParams &p, const LanePassInfo &info, hipS
         BRX_TRY(grow_dev((void **)&w->u_q, cap * 4));
         BRX_TRY(grow_dev((void **)&w->u_qk, cap * 8));
         BRX_TRY(grow_dev((void **)&w->u_res, cap * 32));
+        BRX_TRY(grow_dev((void **)&w->u_desc, cap * sizeof(UnitDesc)));
         w->units_cap = cap;
     }
     if (w->p_cap < p_bound) {
@@ -909,6 +940,7 @@ int lane_pass(brx_chain *ch, const PassParams &p, const LanePassInfo &info, hipS
     a.u_q = w->u_q;
     a.u_qk = w->u_qk;
     a.u_res = w->u_res;
+    a.u_desc = w->u_desc;
     a.P = w->P;
     for (int d = 0; d < MAX_DEPTH; d++)
         a.E[d] = w->E[d];
@@ -931,6 +963,8 @@ int lane_pass(brx_chain *ch, const PassParams &p, const LanePassInfo &info, hipS
             lane_sync_kernel<true><<<blocks, 256, 0, s>>>(a);
         else
             lane_sync_kernel<false><<<blocks, 256, 0, s>>>(a);
+        const uint64_t lb = (units_bound + 255ull) / 256ull;
+        lane_link_kernel<<<(uint32_t)(lb < 4096ull ? lb : 4096ull), 256, 0, s>>>(a);
     }
     {
         KernelTimer t("correct_pass", s);
