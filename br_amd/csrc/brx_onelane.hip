@@ -55,6 +55,9 @@ constexpr uint32_t C_VOID = 0xfffffff2u;   // res[6]: nothing produced
 constexpr int MAX_DEPTH = 3;               // edit lists: own stretch + two stretches scanned after a miss
 constexpr uint32_t MAX_LANE_READ = 1u << 28; // positions are kept in 28 bits of an edit
 constexpr uint32_t LANE_GRAB = 64;           // units a wave draws from the global counter at a time
+#ifndef BRX_LANE_WAVES
+#define BRX_LANE_WAVES 7 // waves per SIMD the automaton is compiled for (tools/ab_build.sh sweeps it)
+#endif
 
 struct UnitDesc;
 struct LaneArgs {
@@ -64,6 +67,7 @@ struct LaneArgs {
     uint32_t *nu;              // units per read                            [n_reads]
     uint64_t *ubase;           // exclusive scan of nu                      [n_reads + 1]
     uint32_t *u_read;          // read of a unit                            [units]
+    uint4 *u_in;               // where its read is: in_at lo, hi, n, j     [units]
     uint32_t *u_q;             // its sync position (0 for a read's first)  [units]
     uint64_t *u_qk;            // the original k-mer in front of it         [units]
     uint32_t *u_res;           // n0 t1 n1 t2 n2 t3 code -                  [8 x units]
@@ -147,8 +151,10 @@ __global__ __launch_bounds__(256) void lane_pack_kernel(LaneArgs a)
         }
         // and the read's units
         const uint64_t ub = a.ubase[r], ue = a.ubase[r + 1];
-        for (uint64_t u = ub + threadIdx.x; u < ue; u += 256)
+        for (uint64_t u = ub + threadIdx.x; u < ue; u += 256) {
             a.u_read[u] = r;
+            a.u_in[u] = make_uint4((uint32_t)at, (uint32_t)(at >> 32), n, (uint32_t)(u - ub));
+        }
     }
 }
 
@@ -184,17 +190,14 @@ __global__ __launch_bounds__(256) void lane_sync_kernel(LaneArgs a)
     const unsigned long long wave = (unsigned long long)blockIdx.x * 4ull + (threadIdx.x >> 6);
     const unsigned long long n_waves = (unsigned long long)gridDim.x * 4ull;
     for (unsigned long long u = wave; u < n_units; u += n_waves) {
-        const uint32_t r = a.u_read[u];
-        const uint32_t j = (uint32_t)(u - a.ubase[r]);
+        const uint4 ui = a.u_in[u]; // (one load instead of unit -> read -> offsets / lengths / unit base)
+        const uint32_t j = ui.w, n = ui.z;
         if (j == 0) {
             if (lane == 0)
                 a.u_q[u] = 0;
             continue;
         }
-        const uint8_t *in;
-        uint32_t n;
-        bool poisoned;
-        (void)read_view(p, r, in, n, poisoned);
+        const uint8_t *in = p.in + (((uint64_t)ui.y << 32) | ui.x);
         const uint32_t s = j * a.C;
         const uint32_t lim = (s + a.C < n) ? s + a.C : n; // k-mers ending at e < lim
         uint32_t q = U_VOID;
@@ -291,10 +294,10 @@ __global__ __launch_bounds__(256) void lane_link_kernel(LaneArgs a)
 //         1 ALTS  probe the trigger k-mer with last base cur   mod.rs:114-128 (the read's own base is known not solid)
 //         2 SCEN  probe corr + seq[off .. off+jj]            exist/mod.rs:33-41  (scenario cur: I / S / D, off = 2 - cur)
 //         3 MORE  probe corr + seq[off .. off+c]             exist/mod.rs:57-66
-enum { S_ST = 0, S_CUR = 2, S_JJ = 4, S_AM = 8, S_PASS = 12, S_FAILM = 16, S_KEEP = 20, S_SKIP = 24, S_PREV = 27, S_FIRST = 28, S_SLOW = 29 };
+enum { S_ST = 0, S_CUR = 2, S_JJ = 4, S_ACC = 8, S_PASS = 12, S_SKIP = 24, S_PREV = 27, S_FIRST = 28, S_SLOW = 29 };
 
 template <bool IDX, int KT>
-__global__ __launch_bounds__(256, 7) void lane_kernel(LaneArgs a)
+__global__ __launch_bounds__(256, BRX_LANE_WAVES) void lane_kernel(LaneArgs a)
 {
     const PassParams &p = a.p;
     const int k = KT ? KT : p.k;
@@ -507,33 +510,30 @@ __global__ __launch_bounds__(256, 7) void lane_kernel(LaneArgs a)
             } else {
                 hop = 0;
                 // ---- transition: every state's successor computed side by side, one select per field ------------------------
-                const uint32_t solb = sol ? 1u : 0u, bit = 1u << cur, above = ~((2u << cur) - 1u);
-                const uint32_t am = (S >> S_AM) & 15u, passm = (S >> S_PASS) & 7u, failm = (S >> S_FAILM) & 7u, keep = (S >> S_KEEP) & 7u;
-                // SCAN (mod.rs:73, 99-102; mod.rs:67 for `first`)
-                const bool accept = is0 && (sol || !prev), trig = is0 && !accept;
-                // ALTS (mod.rs:114-128, exist/mod.rs:121-129): the read's own base is the trigger k-mer, known not solid
-                const uint32_t am1 = am | (solb << cur);
-                uint32_t an = cur + 1u;
-                an += (an == c0) ? 1u : 0u;
-                const bool alts_end = is1 && (an >= 4u || __popc(am1) > 1);
-                // scenarios that cannot read their c look-aheads (exist/mod.rs:27-29): I needs c + 2 bases, S c + 1, D c
-                const uint32_t failm0 = rem >= c + 2u ? 0u : (rem == c + 1u ? 1u : (rem == c ? 3u : 7u));
-                const bool to_scen = alts_end && __popc(am1) == 1 && failm0 != 7u;
-                // SCEN (exist/mod.rs:21-47, :97-109): the score of scenario cur stops at the first k-mer that is not solid
-                const bool s_pass = is2 && sol && jj + 1u == c, s_over = is2 && (!sol || s_pass);
-                const uint32_t pass1 = passm | (s_pass ? bit : 0u), fail1 = failm | ((is2 && !sol) ? bit : 0u);
-                const uint32_t rest_s = 7u & ~fail1 & ~pass1 & above;
-                const bool scen_end = s_over && rest_s == 0u;
-                const bool to_more = scen_end && __popc(pass1) > 1; // several scored c: one base more decides (exist/mod.rs:138-147)
-                // MORE
-                const uint32_t keep1 = keep | (is3 ? solb << cur : 0u);
-                const uint32_t rest_m = passm & above;
-                const bool more_end = is3 && rest_m == 0u;
-                // verdicts
-                const bool apply_b = (scen_end && __popc(pass1) == 1) || (more_end && __popc(keep1) == 1);
-                const bool fail = (alts_end && !to_scen) || (scen_end && pass1 == 0u) || (more_end && __popc(keep1) != 1);
-                const uint32_t win = (uint32_t)__ffs(is2 ? pass1 : keep1) - 1u; // the scenario applied (if apply_b)
-                const uint32_t used = 2u - win;                                // bases of the read it consumes (one.rs:65-71)
+                // The three probing states are one loop over CANDIDATES in rising order -- ALTS: the three bases that are not
+                // the read's own (mod.rs:114-128; its own base is the trigger k-mer, known not solid); SCEN: the scenarios
+                // I, S, D from the first one that can still read its c look-aheads (exist/mod.rs:27-29, :97-109); MORE: the
+                // scenarios that scored c (exist/mod.rs:138-147) -- with one result mask, and one verdict when they run out.
+                const uint32_t solb = sol ? 1u : 0u, above = ~((2u << cur) - 1u);
+                const uint32_t acc = (S >> S_ACC) & 15u, passm = (S >> S_PASS) & 7u;
+                const bool accept = is0 && (sol || !prev), trig = is0 && !accept; // mod.rs:73, :99-102 (:67 for `first`)
+                const uint32_t cands = (is1 ? (15u & ~(1u << c0)) : (is2 ? 7u : passm)) & above;
+                const bool s_pass = is2 && sol && jj + 1u == c;  // get_score == c
+                const bool s_over = is2 && (!sol || s_pass);     // ... or it stops below c (exist/mod.rs:38-42)
+                const uint32_t acc1 = acc | ((is1 || is3) ? solb << cur : 0u);
+                const uint32_t pass1 = passm | (s_pass ? 1u << cur : 0u);
+                const bool adv_c = is1 || is3 || s_over;
+                const bool end = adv_c && (cands == 0u || (is1 && __popc(acc1) > 1));
+                const uint32_t dm = is2 ? pass1 : acc1; // what the verdict looks at: alternatives / scenarios that held
+                const int pc = __popc(dm);
+                const uint32_t win = (uint32_t)__ffs(dm) - 1u;
+                // the first scenario that can read its c look-aheads: I needs c + 2 bases, S c + 1, D c (3: none)
+                const uint32_t smin = rem >= c + 2u ? 0u : (rem == c + 1u ? 1u : (rem == c ? 2u : 3u));
+                const bool to_scen = end && is1 && pc == 1 && smin < 3u; // exist/mod.rs:121-129
+                const bool to_more = end && is2 && pc > 1;
+                const bool apply_b = end && !is1 && pc == 1;             // exist/mod.rs:135-137, :143-144
+                const bool fail = end && !to_scen && !to_more && !apply_b; // exist/mod.rs:123-126, :132-134, :146
+                const uint32_t used = 2u - win; // bases of the read the applied scenario consumes (one.rs:65-71)
                 // The c look-ahead k-mers of the winning scenario ARE the next c scan k-mers, all found solid: the reference's
                 // loop copies these bases with previous = true (mod.rs:99-102).  Jump over them -- unless the unit's target
                 // lies among them: then they are walked one by one (without a probe), so that the state at the target is seen
@@ -543,20 +543,17 @@ __global__ __launch_bounds__(256, 7) void lane_kernel(LaneArgs a)
                 const bool fix = apply_b && room;
                 // the new state word
                 const uint32_t st1 = trig ? 1u : (to_scen ? 2u : (to_more ? 3u : ((fail || apply_b) ? 0u : st)));
-                uint32_t cur1 = is1 ? (an & 3u) : ((s_over && rest_s) ? (uint32_t)__ffs(rest_s) - 1u : ((is3 && rest_m) ? (uint32_t)__ffs(rest_m) - 1u : cur));
-                cur1 = trig ? (c0 == 0u ? 1u : 0u) : (to_scen ? (uint32_t)__ffs(7u & ~failm0) - 1u : (to_more ? (uint32_t)__ffs(pass1) - 1u : cur1));
+                const uint32_t cur1 = trig ? (c0 == 0u ? 1u : 0u)
+                                           : (to_scen ? smin : (to_more ? win : ((adv_c && !end) ? (uint32_t)__ffs(cands) - 1u : cur)));
                 const uint32_t jj1 = (is2 && !s_over) ? jj + 1u : 0u;
-                const uint32_t amn = trig ? 0u : (is1 ? am1 : am);
-                const uint32_t passn = to_scen ? 0u : pass1, failn = to_scen ? failm0 : fail1, keepn = to_more ? 0u : keep1;
+                const uint32_t accn = (trig || to_more) ? 0u : acc1, passn = to_scen ? 0u : pass1;
                 const uint32_t skipn = accept ? (skip ? skip - 1u : 0u) : ((fix && !jump) ? c : skip);
                 const uint32_t prevn = accept ? solb : (fail ? 0u : (apply_b ? 1u : (prev ? 1u : 0u)));
-                S = st1 | (cur1 << S_CUR) | (jj1 << S_JJ) | (amn << S_AM) | (passn << S_PASS) | (failn << S_FAILM) | (keepn << S_KEEP) |
-                    (skipn << S_SKIP) | (prevn << S_PREV);
+                S = st1 | (cur1 << S_CUR) | (jj1 << S_JJ) | (accn << S_ACC) | (passn << S_PASS) | (skipn << S_SKIP) | (prevn << S_PREV);
                 // the k-mers: a failed fix copies the trigger base through and keeps it in the k-mer (mod.rs:91-96)
-                const uint64_t corr_alt = (corr & ~3ull) | (uint64_t)((uint32_t)__ffs(am1) - 1u);
                 const uint64_t kfix = jump ? (((corr << (2u * c)) | (uint64_t)cb) & mask) : corr;
                 kmer = accept ? pk : (fail ? ((corr & ~3ull) | (uint64_t)c0) : (fix ? kfix : kmer));
-                corr = trig ? pk : (to_scen ? corr_alt : corr);
+                corr = trig ? pk : (to_scen ? ((corr & ~3ull) | (uint64_t)win) : corr);
                 const uint32_t adv = accept ? (first ? 0u : 1u) : (fail ? 1u : (fix ? used + (jump ? c : 0u) : 0u));
                 ev |= (trig ? 2u : 0u) | (fix ? 4u : 0u);
                 if (apply_b) { // mod.rs:75-89: one base out, `used` bases of the read consumed -- the lane's only output
@@ -620,7 +617,7 @@ __device__ __forceinline__ void copy_bytes(uint8_t *dst, const uint8_t *src, uin
 // a fix writes one base and consumes `used` bases of the read; everything else is copied through).  Copying is
 // OUTPUT-centric: every thread produces 16 aligned output bytes, finds the fix its first byte lies behind by bisection
 // of the fixes' output offsets (LDS), and in the common case -- no fix inside its 16 bytes -- moves them as one vector.
-constexpr uint32_t AP_EDITS = 2048; // fixes replayed per batch
+constexpr uint32_t AP_EDITS = 1024; // fixes replayed per batch
 constexpr uint32_t AP_PIECES = 256; // pieces (unit, depth) gathered per batch
 
 __global__ __launch_bounds__(256) void lane_apply_kernel(LaneArgs a)
@@ -633,6 +630,10 @@ __global__ __launch_bounds__(256) void lane_apply_kernel(LaneArgs a)
     __shared__ uint32_t pc_off[AP_PIECES + 1]; // ... and how many came before
     __shared__ uint32_t sh_part[256];
     __shared__ uint32_t sh_np, sh_next_u, sh_state;
+    // the records of the read's first 256 units, loaded side by side: the chain is walked by ONE lane, and every
+    // dependent trip to global memory it makes is a microsecond the other 255 wait
+    __shared__ uint4 sh_ra[256], sh_rb[256];
+    __shared__ uint64_t sh_eat[256];
     for (uint32_t r = blockIdx.x; r < p.n_reads; r += gridDim.x) {
         if (p.in_staged && p.in_lens[r] == 0xffffffffu) { // given up by an earlier pass of this attempt: stays poisoned
             if (threadIdx.x == 0)
@@ -652,6 +653,14 @@ __global__ __launch_bounds__(256) void lane_apply_kernel(LaneArgs a)
         uint32_t cur_in = 0; // input bases consumed so far (uniform)
         bool failed = false, more = true;
         uint32_t u_next = ub, d_next = 0; // where the chain walk goes on (uniform)
+        __syncthreads();
+        if (ub + threadIdx.x < (uint32_t)a.ubase[r + 1]) {
+            const uint32_t uu = ub + threadIdx.x;
+            sh_ra[threadIdx.x] = *reinterpret_cast<const uint4 *>(a.u_res + 8ull * uu);
+            sh_rb[threadIdx.x] = *reinterpret_cast<const uint4 *>(a.u_res + 8ull * uu + 4);
+            const uint4 d1 = reinterpret_cast<const uint4 *>(a.u_desc + uu)[1];
+            sh_eat[threadIdx.x] = ((uint64_t)d1.w << 32) | d1.z;
+        }
         while (more && !failed) {
             // ---- gather pieces until the batch is full (lane 0; the others wait) ----------------------------------------
             __syncthreads();
@@ -659,8 +668,9 @@ __global__ __launch_bounds__(256) void lane_apply_kernel(LaneArgs a)
                 uint32_t np = 0, cnt = 0, u = u_next, d = d_next, state = 1; // state: 0 chain done, 1 more to come, 2 failed
                 pc_off[0] = 0;
                 for (;;) {
-                    const uint4 ra = *reinterpret_cast<const uint4 *>(a.u_res + 8ull * u);
-                    const uint4 rb = *reinterpret_cast<const uint4 *>(a.u_res + 8ull * u + 4);
+                    const bool near = u - ub < 256u;
+                    const uint4 ra = near ? sh_ra[u - ub] : *reinterpret_cast<const uint4 *>(a.u_res + 8ull * u);
+                    const uint4 rb = near ? sh_rb[u - ub] : *reinterpret_cast<const uint4 *>(a.u_res + 8ull * u + 4);
                     const uint32_t res[8] = {ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z, rb.w};
                     const uint32_t code = res[6];
                     if (code >= (uint32_t)MAX_DEPTH) { // FAIL, or a void unit on the chain (cannot be)
@@ -675,7 +685,7 @@ __global__ __launch_bounds__(256) void lane_apply_kernel(LaneArgs a)
                             break;
                         }
                         const uint32_t xu = d == 0 ? u : res[2 * d - 1];
-                        pc_src[np] = ((uint64_t)d << 60) | edit_start(in_at, r, ub, xu - ub, a.u_q[xu]);
+                        pc_src[np] = ((uint64_t)d << 60) | (xu - ub < 256u ? sh_eat[xu - ub] : edit_start(in_at, r, ub, xu - ub, a.u_q[xu]));
                         cnt += ne; // (a single piece may hold more than a batch: it is then replayed in several)
                         np++;
                         pc_off[np] = cnt;
@@ -813,6 +823,7 @@ __global__ __launch_bounds__(256) void lane_apply_kernel(LaneArgs a)
 struct LaneWork {
     uint32_t *nu = nullptr, *u_read = nullptr, *u_q = nullptr, *u_res = nullptr, *fail_list = nullptr, *P = nullptr;
     UnitDesc *u_desc = nullptr;
+    uint4 *u_in = nullptr;
     uint32_t *E[MAX_DEPTH] = {nullptr, nullptr, nullptr};
     uint64_t *ubase = nullptr, *u_qk = nullptr;
     uint64_t reads_cap = 0, units_cap = 0, p_cap = 0, e_cap = 0;
@@ -857,7 +868,7 @@ void lane_ws_free(brx_chain *ch)
     LaneWork *w = (LaneWork *)ch->lane_ws;
     if (!w)
         return;
-    for (void *q : {(void *)w->u_desc, (void *)w->nu, (void *)w->u_read, (void *)w->u_q, (void *)w->u_res, (void *)w->fail_list, (void *)w->P,
+    for (void *q : {(void *)w->u_in, (void *)w->u_desc, (void *)w->nu, (void *)w->u_read, (void *)w->u_q, (void *)w->u_res, (void *)w->fail_list, (void *)w->P,
                     (void *)w->E[0], (void *)w->E[1], (void *)w->E[2], (void *)w->ubase, (void *)w->u_qk})
         if (q)
             (void)hipFree(q);
@@ -875,10 +886,12 @@ int lane_pass(brx_chain *ch, const PassParams &p, const LanePassInfo &info, hipS
         return BRX_ERR_UNSUPPORTED;
     // chunk length: enough units to keep ~4.6e5 lanes busy a few times over, not so short that the stretch a unit's
     // predecessor re-scans in front of its sync point (a few dozen bases) becomes the larger part
-    constexpr uint64_t RESIDENT = 256ull * 4ull * 7ull * 64ull;
+    constexpr uint64_t RESIDENT = 256ull * 4ull * BRX_LANE_WAVES * 64ull;
     uint32_t C = env_u32("BRX_LANE_CHUNK", 0u);
     if (C == 0u) {
-        const uint64_t want = info.in_total_bound / (2ull * RESIDENT);
+        // (measured at configs[1], same box: 256 -> 11.7 ms per launch, 512 -> 11.65, 768 -> 12.4, 1090 -> 12.6, 2048 -> 16.7:
+        // a lane should get about four units, or the lanes that got one more than the others run the tail alone)
+        const uint64_t want = info.in_total_bound / (4ull * RESIDENT);
         C = want < 256ull ? 256u : (want > 2048ull ? 2048u : (uint32_t)want);
     }
     if (C < 64u)
@@ -913,6 +926,7 @@ int lane_pass(brx_chain *ch, const PassParams &p, const LanePassInfo &info, hipS
         BRX_TRY(grow_dev((void **)&w->u_qk, cap * 8));
         BRX_TRY(grow_dev((void **)&w->u_res, cap * 32));
         BRX_TRY(grow_dev((void **)&w->u_desc, cap * sizeof(UnitDesc)));
+        BRX_TRY(grow_dev((void **)&w->u_in, cap * 16));
         w->units_cap = cap;
     }
     if (w->p_cap < p_bound) {
@@ -941,6 +955,7 @@ int lane_pass(brx_chain *ch, const PassParams &p, const LanePassInfo &info, hipS
     a.u_qk = w->u_qk;
     a.u_res = w->u_res;
     a.u_desc = w->u_desc;
+    a.u_in = w->u_in;
     a.P = w->P;
     for (int d = 0; d < MAX_DEPTH; d++)
         a.E[d] = w->E[d];
@@ -969,7 +984,7 @@ int lane_pass(brx_chain *ch, const PassParams &p, const LanePassInfo &info, hipS
     {
         KernelTimer t("correct_pass", s);
         const uint64_t want = (units_bound + 255ull) / 256ull;
-        const uint32_t blocks = (uint32_t)(want < 256ull * 7ull ? want : 256ull * 7ull);
+        const uint32_t blocks = (uint32_t)(want < 256ull * BRX_LANE_WAVES ? want : 256ull * BRX_LANE_WAVES);
         if (idx)
             launch_lane<true>(a, blocks, s);
         else
