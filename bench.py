@@ -303,12 +303,13 @@ def main():
                     "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": alg_bytes[dominant],
                     "launches": prof[dominant]["launches"]}
 
-    cpu = e2e = None
+    cpu = e2e = host = None
     if rank == 0 and world == 1:
         # free the bench's own HBM/host buffers are not needed any more; the legs below bring their own
         # the file-to-file leg first: behind the CPU baseline (16 threads for ~20 s, an 8 GiB table allocated and freed) its
         # host stages measured 3-8x slower on the same box (build 1.0 s instead of 0.16 s per Gbp)
         if not args.no_e2e and args.config == 1 and n_reads <= 200_000:
+            host = host_8192(args, d_bases, d_off, n_reads, gs)
             e2e = e2e_fasta(args, d_bases, d_off, n_reads, total, k, a)
         if not args.no_cpu_baseline:
             cpu = cpu_baseline(args, cfg, gs, k, n_reads)
@@ -345,6 +346,7 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu,
             "e2e": e2e,
+            "host_8192": host,
         }
         print(json.dumps(line))
     if exchanger is not None and hasattr(exchanger, "close"):
@@ -444,6 +446,57 @@ def cpu_baseline(args, cfg, gs, k, n_reads):
     except MemoryError:
         res["set_build"] = {"value": None, "sample": "host table of k=%d did not fit" % kb}
     return res
+
+
+def host_8192(args, d_bases, d_off, n_reads, gs):
+    """The boundary the reference would call: brx_chain_correct_batch on HOST buffers of 8192 records, the batch size
+    of run_correction / populate_buffer (src/lib.rs:90,168-188) -- upload, both passes, download, per call.  Twice: the
+    batches in ordinary (pageable) memory, and in brx_host_alloc (page-locked) blocks.  PCIe-inclusive: never `value`."""
+    import ctypes as C
+    import numpy as np
+    import br_amd
+    from br_amd import _lib
+    L = _lib.lib()
+    per, n_b = 8192, 4
+    if n_reads < per * (n_b + 1):
+        return None
+    try:
+        off_all = d_off[:per * (n_b + 1) + 1].cpu().numpy().astype(np.uint64)
+        bases_all = d_bases[:int(off_all[-1])].cpu().numpy()
+        chain = br_amd.Chain(gs, [(m, args.confirm, 7) for m in args.methods], two_side=False)
+        res = {"records_per_batch": per, "batches": n_b}
+        for kind in ("pageable", "pinned"):
+            bufs, keep = [], []
+            for b in range(n_b + 1):
+                lo, hi = int(off_all[b * per]), int(off_all[(b + 1) * per])
+                offs = np.ascontiguousarray(off_all[b * per:(b + 1) * per + 1] - off_all[b * per])
+                if kind == "pinned":
+                    ptr = L.brx_host_alloc(hi - lo)
+                    keep.append(ptr)
+                    C.memmove(ptr, bases_all[lo:hi].ctypes.data, hi - lo)
+                    bufs.append((ptr, offs, hi - lo))
+                else:
+                    piece = bases_all[lo:hi].copy()
+                    bufs.append((piece.ctypes.data, offs, hi - lo, piece))
+            ob, oo = C.POINTER(C.c_uint8)(), C.POINTER(C.c_uint64)()
+            def one(bf):
+                _lib.check(L.brx_chain_correct_batch(chain._h, bf[0], bf[1].ctypes.data, per, C.byref(ob), C.byref(oo)))
+                L.brx_buf_free(ob)
+                L.brx_buf_free(oo)
+            one(bufs[n_b])  # warm-up: workspace, page-locked pool
+            t0 = time.perf_counter()
+            for b in range(n_b):
+                one(bufs[b])
+            dt = time.perf_counter() - t0
+            nb = sum(bf[2] for bf in bufs[:n_b])
+            res[kind] = {"gbases_per_s": round(nb / dt / 1e9, 3), "ms_per_batch": round(dt / n_b * 1e3, 2)}
+            for ptr in keep:
+                L.brx_host_free(ptr)
+        res["value"] = res["pinned"]["gbases_per_s"]
+        res["unit"] = "Gbases/s"
+        return res
+    except Exception as e:
+        return {"value": None, "error": "%s: %s" % (type(e).__name__, e)}
 
 
 def e2e_fasta(args, d_bases, d_off, n_reads, total, k, a):

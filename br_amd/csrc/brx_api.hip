@@ -121,6 +121,88 @@ KernelTimer::~KernelTimer()
     g_slots[slot_].pending.emplace_back(start_, stop_);
 }
 
+// ---- page-locked host buffers: what the host-buffer entry points hand back, and what callers may fill ---------------
+// A copy between HBM and PAGEABLE host memory goes through the runtime's own bounce buffers at 6-10 GB/s: 82 MB each
+// way per 8192-record batch was 2/3 of brx_chain_correct_batch's 31 ms (tools/host_rate.py, round 2).  Page-locked memory
+// moves at PCIe speed and asynchronously; hipHostMalloc itself costs milliseconds, so the blocks are pooled: a block
+// released by brx_buf_free / brx_host_free is kept (up to POOL_KEEP bytes) for the next batch.
+namespace {
+struct HostBlock {
+    void *p;
+    size_t cap;
+    bool used;
+};
+std::mutex g_hostpool_mu;
+std::vector<HostBlock> g_hostpool;
+constexpr size_t POOL_KEEP = 1ull << 30;
+}
+
+void *host_buf_acquire(size_t bytes)
+{
+    {
+        std::lock_guard<std::mutex> g(g_hostpool_mu);
+        int best = -1;
+        for (int i = 0; i < (int)g_hostpool.size(); i++)
+            if (!g_hostpool[i].used && g_hostpool[i].cap >= bytes && g_hostpool[i].cap <= 2 * bytes + (1u << 20) &&
+                (best < 0 || g_hostpool[i].cap < g_hostpool[best].cap))
+                best = i;
+        if (best >= 0) {
+            g_hostpool[best].used = true;
+            return g_hostpool[best].p;
+        }
+    }
+    void *p = nullptr;
+    const size_t cap = bytes + bytes / 8 + 4096; // batches of a stream differ by a few percent: let the next one fit
+    if (hipHostMalloc(&p, cap, hipHostMallocDefault) != hipSuccess || !p) {
+        // no GPU runtime / no lockable memory left: plain memory still works, only slower
+        p = malloc(bytes);
+        return p;
+    }
+    std::lock_guard<std::mutex> g(g_hostpool_mu);
+    g_hostpool.push_back(HostBlock{p, cap, true});
+    return p;
+}
+
+void host_buf_release(void *p)
+{
+    if (!p)
+        return;
+    void *drop = nullptr;
+    {
+        std::lock_guard<std::mutex> g(g_hostpool_mu);
+        size_t idle = 0;
+        int at = -1;
+        for (int i = 0; i < (int)g_hostpool.size(); i++) {
+            if (g_hostpool[i].p == p)
+                at = i;
+            else if (!g_hostpool[i].used)
+                idle += g_hostpool[i].cap;
+        }
+        if (at < 0) { // not one of ours: it came from malloc
+            drop = nullptr;
+        } else if (idle + g_hostpool[at].cap > POOL_KEEP) {
+            drop = g_hostpool[at].p;
+            g_hostpool.erase(g_hostpool.begin() + at);
+            (void)hipHostFree(drop);
+            return;
+        } else {
+            g_hostpool[at].used = false;
+            return;
+        }
+    }
+    free(p);
+}
+
+bool host_buf_is_pinned(const void *p)
+{
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) {
+        (void)hipGetLastError(); // (an ordinary malloc'ed pointer: the query fails and leaves a sticky-looking error behind)
+        return false;
+    }
+    return at.type == hipMemoryTypeHost;
+}
+
 } // namespace brx
 
 using namespace brx;
@@ -214,6 +296,10 @@ int brx_profile_names(char *buf, size_t cap)
     return BRX_OK;
 }
 
-void brx_buf_free(void *p) { free(p); }
+void brx_buf_free(void *p) { brx::host_buf_release(p); }
+
+void *brx_host_alloc(size_t bytes) { return brx::host_buf_acquire(bytes ? bytes : 1); }
+
+void brx_host_free(void *p) { brx::host_buf_release(p); }
 
 } // extern "C"

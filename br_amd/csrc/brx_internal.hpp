@@ -32,6 +32,10 @@ void set_error(const char *fmt, ...);
 
 // BRX_OK if `device` is a usable GPU and has been made current
 int use_device(int device);
+// pooled page-locked host memory (brx_api.hip): what brx_host_alloc and the callee-allocated outputs are made of
+void *host_buf_acquire(size_t bytes);
+void host_buf_release(void *p);
+bool host_buf_is_pinned(const void *p);
 
 // BRX_TRACE=1: synchronise `s` and print a time-stamped stage name on stderr (finding where a big job stalls)
 void trace_stage(hipStream_t s, const char *what);
@@ -163,5 +167,7 @@ struct brx_chain {
     brx_chain *sub = nullptr;
     bool is_sub = false;
     void *lane_ws = nullptr; // workspace of the lane-per-chunk pass (brx_onelane.hip)
+    uint8_t *h_in = nullptr; // page-locked bounce block for batches handed over in pageable memory
+    uint64_t h_in_cap = 0;
     std::mutex mu;
 };

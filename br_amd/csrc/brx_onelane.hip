@@ -189,8 +189,11 @@ __global__ __launch_bounds__(256) void lane_sync_kernel(LaneArgs a)
     const unsigned long long n_units = p.ctrl[CTL_LANE_UNITS];
     const unsigned long long wave = (unsigned long long)blockIdx.x * 4ull + (threadIdx.x >> 6);
     const unsigned long long n_waves = (unsigned long long)gridDim.x * 4ull;
+    uint4 ui_next = wave < n_units ? a.u_in[wave] : make_uint4(0, 0, 0, 0);
     for (unsigned long long u = wave; u < n_units; u += n_waves) {
-        const uint4 ui = a.u_in[u]; // (one load instead of unit -> read -> offsets / lengths / unit base)
+        const uint4 ui = ui_next; // (one load instead of unit -> read -> offsets / lengths / unit base; loaded an iteration ahead)
+        if (u + n_waves < n_units)
+            ui_next = a.u_in[u + n_waves];
         const uint32_t j = ui.w, n = ui.z;
         if (j == 0) {
             if (lane == 0)
@@ -628,7 +631,7 @@ __global__ __launch_bounds__(256) void lane_apply_kernel(LaneArgs a)
     __shared__ uint32_t e_in[AP_EDITS];      // input position where that stretch starts
     __shared__ uint64_t pc_src[AP_PIECES];   // pieces: where their fixes are (list index << 60 | entry)
     __shared__ uint32_t pc_off[AP_PIECES + 1]; // ... and how many came before
-    __shared__ uint32_t sh_part[256];
+    __shared__ uint32_t sh_part[4];
     __shared__ uint32_t sh_np, sh_next_u, sh_state;
     // the records of the read's first 256 units, loaded side by side: the chain is walked by ONE lane, and every
     // dependent trip to global memory it makes is a microsecond the other 255 wait
@@ -741,20 +744,23 @@ __global__ __launch_bounds__(256) void lane_apply_kernel(LaneArgs a)
                     e_in[t] = prev_end;
                     part += ((e >> 4) - prev_end) + 1u;
                 }
-                sh_part[threadIdx.x] = part;
-                __syncthreads();
-                for (int o = 1; o < 256; o <<= 1) { // inclusive scan of the 256 partial sums
-                    const uint32_t v = threadIdx.x >= (uint32_t)o ? sh_part[threadIdx.x - o] : 0u;
-                    __syncthreads();
-                    sh_part[threadIdx.x] += v;
-                    __syncthreads();
+                uint32_t inc = part; // inclusive scan of the 256 partial sums: inside the wave by shuffles, then the four waves
+                for (int o = 1; o < 64; o <<= 1) {
+                    const uint32_t v = __shfl_up(inc, o);
+                    if ((int)(threadIdx.x & 63u) >= o)
+                        inc += v;
                 }
-                uint32_t run = sh_part[threadIdx.x] - part;
+                if ((threadIdx.x & 63u) == 63u)
+                    sh_part[threadIdx.x >> 6] = inc;
+                __syncthreads();
+                uint32_t run = inc - part;
+                for (uint32_t q = 0; q < (threadIdx.x >> 6); q++)
+                    run += sh_part[q];
+                const uint32_t batch_total = sh_part[0] + sh_part[1] + sh_part[2] + sh_part[3];
                 for (uint32_t t = t0; t < t1; t++) {
                     e_os[t] = run;
                     run += ((e_raw[t] >> 4) - e_in[t]) + 1u;
                 }
-                const uint32_t batch_total = sh_part[255];
                 if (threadIdx.x == 0)
                     e_os[nb] = batch_total;
                 __syncthreads();

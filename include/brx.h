@@ -252,6 +252,13 @@ int brx_chain_correct_batch_device(brx_chain_t *chain, const uint8_t *d_bases, c
 int brx_chain_last_stats(const brx_chain_t *chain, uint64_t *stats8);
 void brx_chain_free(brx_chain_t *chain);
 void brx_buf_free(void *p);
+/* Page-locked host memory for batch buffers.  brx_chain_correct_batch / brx_set_count_add_batch accept ANY host
+ * pointer, but a batch in pageable memory is first copied into a page-locked block by the library (the DMA engines
+ * read nothing else at full speed); a caller that fills buffers from brx_host_alloc -- the reference's
+ * populate_buffer, src/lib.rs:168-188, is the natural place -- skips that copy.  The blocks are pooled; release with
+ * brx_host_free (or brx_buf_free: the callee-allocated outputs of the batch entries are the same kind of block).      */
+void *brx_host_alloc(size_t bytes);
+void brx_host_free(void *p);
 
 /* ---- host pipelines over file descriptors ----------------------------------------
  * run_correction (src/lib.rs:22-139) for ONE input/output pair: FASTA records are parsed from in_fd (plain
