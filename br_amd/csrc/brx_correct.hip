@@ -316,7 +316,7 @@ __device__ __forceinline__ uint32_t scen_width(uint32_t sub, uint32_t c, int G, 
     return left < cap ? left : cap;
 }
 
-template <int G, int M>
+template <int G, int M, bool LIST = false>
 // One fits 80 VGPRs without spilling: 6 waves per SIMD instead of 5 (the kernel waits on memory 60 % of the
 // time, measured 8 % faster), and its 64-lane form (no group shuffles to keep) fits 72: 7 waves; the other methods
 // keep the compiler's own choice
@@ -380,12 +380,13 @@ __global__ __launch_bounds__(256, (M == BRX_ONE ? (G == 64 ? 7 : 6) : (M == BRX_
             if (gl == 0)
                 w = atomicAdd(p.ctrl + CTL_WORK, 1ull);
             w = __shfl(w, gshift);
-            if (w >= (unsigned long long)p.n_reads) {
+            // LIST: the reads of a list made on the device (what the lane-per-chunk pass handed back)
+            if (w >= (LIST ? *p.only_n : (unsigned long long)p.n_reads)) {
                 have = false;
                 return;
             }
             have = true;
-            r = (uint32_t)w;
+            r = LIST ? p.only[w] : (uint32_t)w;
             const uint64_t o0 = p.offsets[r], o1 = p.offsets[r + 1];
             if (p.in_staged) {
                 in = p.in + slot_of(o0, r, p.slack);
@@ -1940,6 +1941,21 @@ void launch_one(const PassParams &p, uint32_t blocks, hipStream_t s)
 } // namespace
 
 namespace brx {
+// Graph's / GapSize's group kernel over the reads p.only[0 .. *p.only_n) (8-lane groups; the visited lists of the chain
+// are sized for pass_blocks(n_reads, walk_group()) blocks of groups at least as wide, so the grid stays inside them)
+int launch_walk_list(const PassParams &p, int method, hipStream_t s)
+{
+    const uint64_t sized_groups = (uint64_t)pass_blocks(p.n_reads, walk_group()) * (256u / (uint32_t)walk_group());
+    uint32_t bl = (uint32_t)(sized_groups / 32u); // 32 eight-lane groups per block (the chain sizes at least 32 lists)
+    bl = bl < 1u ? 1u : (bl > 128u ? 128u : bl);
+    if (method == BRX_GRAPH)
+        correct_kernel<8, BRX_GRAPH, true><<<bl, 256, 0, s>>>(p);
+    else
+        correct_kernel<8, BRX_GAP_SIZE, true><<<bl, 256, 0, s>>>(p);
+    BRX_HIP(hipGetLastError());
+    return BRX_OK;
+}
+
 // One's group kernel over the reads p.only[0 .. *p.only_n): what the lane-per-chunk pass could not stitch
 int launch_one_list(const PassParams &p, hipStream_t s)
 {
@@ -2279,7 +2295,9 @@ static int correct_batch_device_locked(brx_chain_t *ch, const uint8_t *d_bases, 
             // one visited list per group that can be resident: walking methods run 16-lane groups or wider, so a grid of
             // pass_blocks(n_reads, 16) blocks of 16 groups bounds every width (a handful of redone reads needs a
             // handful of lists, not 32768 of them)
-            const uint64_t n_groups = (uint64_t)pass_blocks(n_reads, walk_group()) * (256u / (uint32_t)walk_group());
+            uint64_t n_groups = (uint64_t)pass_blocks(n_reads, walk_group()) * (256u / (uint32_t)walk_group());
+            if (n_groups < 32u)
+                n_groups = 32u; // (one block of the list kernel, launch_walk_list)
             BRX_TRY(ensure((void **)&ch->d_path, &ch->path_bytes, n_groups * maxpath * 8ull));
         }
         const uint64_t stage_need = total_bases + (total_bases >> 2) * slack + 64ull * ((uint64_t)n_reads + 1) + 64;
@@ -2335,9 +2353,10 @@ static int correct_batch_device_locked(brx_chain_t *ch, const uint8_t *d_bases, 
                 p.max_search = 0;
                 p.g_dim = 0;
                 p.g_lds_bytes = 0;
-                if (mth == BRX_ONE && dir == 0 && !p.flip) {
-                    // One's forward pass: one lane per chunk of a read (brx_onelane.hip) where that form applies
-                    const LanePassInfo info{cur_staged ? ch->stage_bytes : total_bases};
+                if ((mth == BRX_ONE || mth == BRX_GRAPH || mth == BRX_GAP_SIZE) && dir == 0 && !p.flip) {
+                    // forward passes of One, Graph and GapSize: one lane per chunk of a read (brx_onelane.hip) where that
+                    // form applies
+                    const LanePassInfo info{cur_staged ? ch->stage_bytes : total_bases, mth};
                     const int lst = lane_pass(ch, p, info, s);
                     if (lst != BRX_OK && lst != BRX_ERR_UNSUPPORTED)
                         return lst;

@@ -90,6 +90,7 @@ __device__ __forceinline__ uint64_t lane_kmer64_dpp(uint64_t carry, uint32_t cod
 
 struct LanePassInfo {
     uint64_t in_total_bound; // upper bound of the pass's input bases (sizes the unit tables and the unit staging)
+    int method;              // BRX_ONE, BRX_GRAPH or BRX_GAP_SIZE
 };
 // One's forward pass, one lane per chunk of a read (brx_onelane.hip).  BRX_ERR_UNSUPPORTED: not applicable to this
 // pass (the caller runs the group kernel instead).
@@ -97,5 +98,6 @@ int lane_pass(brx_chain *ch, const PassParams &p, const LanePassInfo &info, hipS
 void lane_ws_free(brx_chain *ch);
 // the group kernel over a list of reads (p.only / p.only_n), brx_correct.hip
 int launch_one_list(const PassParams &p, hipStream_t s);
+int launch_walk_list(const PassParams &p, int method, hipStream_t s);
 
 } // namespace brx

@@ -74,6 +74,8 @@ struct LaneArgs {
     UnitDesc *u_desc;          // what a lane loads to start on a unit      [units]
     uint32_t *P;               // the batch as 2-bit codes, 16 bases per dword, first base in the top bits
     uint32_t *E[MAX_DEPTH];    // edit lists: pos << 4 | consumed << 2 | base
+    uint2 *EW[MAX_DEPTH];      // the walking correctors' lists: pos, consumed << 16 | bases written (same memory as E)
+    uint32_t *BW[MAX_DEPTH];   // ... and the written bases, 16 per word, a fix starting a word
     uint32_t *fail_list;       // reads handed back to the group kernel     [n_reads]
 };
 
@@ -614,6 +616,434 @@ __device__ __forceinline__ void copy_bytes(uint8_t *dst, const uint8_t *src, uin
         dst[j] = src[j];
 }
 
+// ---- the automaton for the walking correctors: correct::Graph and correct::GapSize -----------------------------------
+// Reference: Graph::correct_error (src/correct/graph.rs:44-85), error_len / alt_nucs / next_nucs (src/correct/mod.rs:
+// 114-152), GapSize::correct_error and ins_sub_correction (src/correct/gap_size.rs:44-108; its `one` branch is
+// Exist<ScenarioOne>, as in lane_kernel above).
+//
+// The same round -- one KmerSet::get, one transition -- with three more kinds of question:
+//   ERRLEN  add(ek, seq[i0 + j]): how far the next solid k-mer is (mod.rs:130-152); the window is read on past the
+//           trigger, a copy of it as it stood at the trigger is kept for what comes back to i0 (ALTS, the One branch, a
+//           failed fix);
+//   WALK    add(wk, b) for the four bases b in turn = next_nucs(wk) (mod.rs:118-128); exactly one solid successor makes a
+//           step: the base joins the path, and the walk ends at first_correct_kmer (Graph) or after gap steps (GapSize);
+//   and SCAN / ALTS / SCEN / MORE as before.
+// Loop-top state.  All k-mers a walk emits are solid (they come out of next_nucs), so after any fix `previous` is
+// get(kmer) here too and the scan can be cut into units at the same sync points.
+// Graph's visited set (graph.rs:47, 71-75) only decides WHEN a walk that entered a cycle gives up: the walk is
+// deterministic, so any cycle detector returns the same None -- Brent's here, O(1) state; a walk whose corrected k-mer
+// already IS first_correct_kmer can only come back to it as a revisit, i.e. end in None, and is not walked at all (nor
+// is one whose error_len ran off the read: its target is not solid and can never be reached).  GapSize's fixed-length
+// walk needs the exact rule (a late detection could run past its end): its <= 31 steps are kept as 2-bit codes in a
+// register and every earlier k-mer is rebuilt from them for the comparison; longer gaps go back to the group kernel.
+// What a fix writes: an entry (position, bases of the read consumed, bases written) and the written bases, 16 per word.
+enum { W_ST = 0, W_CUR = 3, W_JJ = 5, W_ACC = 8, W_PASS = 12, W_MODE = 15, W_HITEND = 17, W_SKIP = 24, W_PREV = 27, W_FIRST = 28, W_SLOW = 29 };
+enum { WS_SCAN = 0, WS_ALTS = 1, WS_SCEN = 2, WS_MORE = 3, WS_ERRLEN = 4, WS_WALK = 5 };
+enum { WM_GRAPH = 0, WM_ONE = 1, WM_INSSUB = 2 };
+#ifndef BRX_WALK_WAVES
+#define BRX_WALK_WAVES 4
+#endif
+
+template <bool IDX, int KT, int M>
+__global__ __launch_bounds__(256, BRX_WALK_WAVES) void lane_walk_kernel(LaneArgs a)
+{
+    const PassParams &p = a.p;
+    const int k = KT ? KT : p.k;
+    const uint32_t c = (uint32_t)p.c; // 1 .. 5 (GapSize's One branch; Graph ignores it)
+    const uint64_t mask = kmask(k);
+    const unsigned long long n_units = p.ctrl[CTL_LANE_UNITS];
+    __shared__ uint4 lc[4][256];
+    const uint32_t tid = threadIdx.x;
+
+    bool have = false, want = true;
+    uint32_t u = 0, n = 0, i = 0, tgt = 0, t1 = U_END;
+    uint64_t tgtk = 0;
+    uint32_t depth = 0, ne = 0, ecap = 0, bw = 0, bw0 = 0;
+    uint64_t eat = 0;
+    uint64_t wreg = 0, wsave = 0;
+    uint32_t wcnt = 0, nextw = 0, pidx = 0, wcnt_s = 0, nextw_s = 0, pidx_s = 0, pbase = 0;
+    uint64_t kmer = 0, corr = 0, wk = 0, fc = 0, tort = 0; // tort: Brent's tortoise (Graph) / the walked bases (GapSize)
+    uint32_t S = 0, hop = 0, cline = 0xffffffffu;
+    uint32_t elen = 0, bpow = 1, blam = 0, np = 0, pacc = 0;
+    uint32_t n_rounds = 0, n_probes = 0, n_trig = 0, n_fix = 0, n_miss = 0;
+    uint32_t wnext = 0, wend = 0;
+
+    for (;;) {
+        uint32_t ev = 0;
+        const bool at_end = have && (S & 7u) == 0u && i >= tgt;
+        if (__any(at_end || want)) {
+            if (at_end) {
+                uint32_t *res = a.u_res + 8ull * u;
+                res[2 * depth] = ne;
+                res[2 * depth + 1] = t1;
+                if (t1 == U_END || (i == tgt && kmer == tgtk)) {
+                    res[6] = depth;
+                    want = true;
+                } else if (depth + 1 < (uint32_t)MAX_DEPTH) {
+                    ev |= 8u;
+                    depth++;
+                    const uint4 *dp = reinterpret_cast<const uint4 *>(a.u_desc + t1);
+                    const uint4 d0 = dp[0], d1 = dp[1], d2 = dp[2];
+                    t1 = d0.z;
+                    tgt = d0.w;
+                    tgtk = ((uint64_t)d1.y << 32) | d1.x;
+                    eat = ((uint64_t)d1.w << 32) | d1.z;
+                    ecap = d2.z;
+                    ne = 0;
+                    bw = 0;
+                } else {
+                    res[6] = C_FAIL;
+                    want = true;
+                }
+            }
+            for (;;) {
+                const uint64_t wm = __ballot(want);
+                if (!wm)
+                    break;
+                if (wnext == wend) {
+                    unsigned long long base = 0;
+                    if ((tid & 63u) == 0u)
+                        base = atomicAdd(p.ctrl + CTL_LANE_WORK, (unsigned long long)LANE_GRAB);
+                    base = __shfl(base, 0);
+                    wnext = base < n_units ? (uint32_t)base : (uint32_t)n_units;
+                    wend = base + LANE_GRAB < n_units ? (uint32_t)(base + LANE_GRAB) : (uint32_t)n_units;
+                    if (wnext == wend) {
+                        if (want)
+                            have = false;
+                        want = false;
+                        break;
+                    }
+                }
+                const uint32_t rank = (uint32_t)__builtin_popcountll(wm & ((1ull << (tid & 63u)) - 1ull));
+                const uint32_t avail = wend - wnext;
+                const uint32_t asked = (uint32_t)__builtin_popcountll(wm);
+                const bool take = want && rank < avail;
+                const uint32_t my = wnext + rank;
+                wnext += asked < avail ? asked : avail;
+                if (take) {
+                    want = false;
+                    have = true;
+                    u = my;
+                    const uint4 *dp = reinterpret_cast<const uint4 *>(a.u_desc + u);
+                    const uint4 d0 = dp[0], d1 = dp[1], d2 = dp[2];
+                    n = d0.x;
+                    const uint32_t q = d0.y;
+                    if (q >= U_VOID - 1u) {
+                        a.u_res[8ull * u + 6] = q == U_VOID ? C_VOID : C_FAIL;
+                        have = false;
+                        want = true;
+                    } else {
+                        t1 = d0.z;
+                        tgt = d0.w;
+                        tgtk = ((uint64_t)d1.y << 32) | d1.x;
+                        eat = ((uint64_t)d1.w << 32) | d1.z;
+                        const uint64_t pw = ((uint64_t)d2.y << 32) | d2.x;
+                        ecap = d2.z;
+                        depth = 0;
+                        ne = 0;
+                        bw = 0;
+                        hop = 0;
+                        pbase = (uint32_t)pw - (q >> 4); // the read's first dword in P
+                        wreg = (((uint64_t)a.P[pw] << 32) | a.P[pw + 1]) << ((q & 15u) * 2u);
+                        wcnt = 32u - (q & 15u);
+                        nextw = a.P[pw + 2];
+                        pidx = (uint32_t)pw + 3u;
+                        if (d2.w) {
+                            if (n < (uint32_t)k) {
+                                uint32_t *res = a.u_res + 8ull * u;
+                                res[0] = 0;
+                                res[1] = U_END;
+                                res[6] = 0;
+                                have = false;
+                                want = true;
+                            } else {
+                                kmer = wreg >> (64 - 2 * k);
+                                wreg <<= 2 * k;
+                                wcnt -= (uint32_t)k;
+                                i = (uint32_t)k;
+                                S = 1u << W_FIRST;
+                            }
+                        } else {
+                            i = q;
+                            kmer = a.u_qk[u];
+                            S = 1u << W_PREV;
+                        }
+                    }
+                }
+            }
+            if (!__any(have))
+                break;
+        }
+        const bool act = have && !((S & 7u) == 0u && i >= tgt);
+        n_rounds += (uint32_t)__builtin_popcountll(__ballot(act));
+        if (act) {
+            if (wcnt <= 16u) {
+                wreg |= (uint64_t)nextw << (32u - 2u * wcnt);
+                wcnt += 16u;
+                nextw = a.P[pidx];
+                pidx++;
+            }
+            const uint32_t st = S & 7u, cur = (S >> W_CUR) & 3u, jj = (S >> W_JJ) & 7u, skip = (S >> W_SKIP) & 7u;
+            const uint32_t mode = (S >> W_MODE) & 3u;
+            const bool prev = (S >> W_PREV) & 1u, first = (S >> W_FIRST) & 1u, slow = (S >> W_SLOW) & 1u;
+            const bool is_scan = st == WS_SCAN, is_alts = st == WS_ALTS, is_scen = st == WS_SCEN, is_more = st == WS_MORE,
+                       is_errlen = st == WS_ERRLEN, is_walk = st == WS_WALK;
+            // SCAN and ERRLEN read the window where it is; everything else looks at the bases from the trigger on
+            const bool live = is_scan || is_errlen;
+            const uint32_t cw = (uint32_t)((live ? wreg : wsave) >> 48);
+            const uint32_t c0 = cw >> 14;
+            const uint32_t rem = n - i; // (i stays at the trigger until it is resolved)
+
+            // ---- the k-mer this state asks about ------------------------------------------------------------------------
+            const uint32_t off = 2u - cur;
+            const uint32_t nb = (is_scan ? (first ? 0u : 1u) : (is_errlen ? 1u : (is_scen ? jj + 1u : (is_more ? c + 1u : 0u))));
+            const uint32_t b0 = (is_scen || is_more) ? off : 0u;
+            const uint32_t wbits = (cw >> (16u - 2u * (b0 + nb))) & ((1u << (2u * nb)) - 1u);
+            const uint64_t base_k = is_scan ? kmer : ((is_errlen || is_walk) ? wk : corr);
+            uint64_t pk = ((base_k << (2u * nb)) | (uint64_t)wbits) & mask;
+            pk = is_alts ? ((pk & ~3ull) | (uint64_t)cur) : (is_walk ? (((pk << 2) & mask) | (uint64_t)cur) : pk);
+            // error_len stops without a probe where the read ends (mod.rs:137-139)
+            const bool el_end = is_errlen && elen + 1u >= rem;
+            const bool need = !(is_scan && skip != 0u) && !(is_more && !(rem > c + off + 1u)) && !el_end;
+            ev |= need ? 1u : 0u;
+
+            // ---- KmerSet::get -------------------------------------------------------------------------------------------
+            bool sol = is_scan && !need, unres = false;
+            if (IDX) {
+                uint64_t key;
+                const uint32_t home = index_locate(p.idx, pk, k, key);
+                const uint32_t line = (home + hop) & (0xffffffffu >> p.idx.line_shift);
+                if (need && !slow && line != cline) {
+                    const uint8_t *L = reinterpret_cast<const uint8_t *>(p.idx.lines + (uint64_t)line * 8ull);
+                    const uint32_t wb = tid & ~63u;
+#pragma unroll
+                    for (int e = 0; e < 4; e++)
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(L + 16 * e),
+                                                         (__attribute__((address_space(3))) void *)&lc[e][wb], 16, 0, 0);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    cline = line;
+                }
+                if (need && slow) {
+                    const uint64_t h = key - 1ull;
+                    sol = (p.bits[h >> 5] >> (h & 31u)) & 1u;
+                } else if (need) {
+                    const uint4 q0 = lc[0][tid], q1 = lc[1][tid], q2 = lc[2][tid], q3 = lc[3][tid];
+                    const uint32_t klo = (uint32_t)key, khi = (uint32_t)(key >> 32);
+                    const bool found = ((q0.x == klo) & (q0.y == khi)) | ((q0.z == klo) & (q0.w == khi)) | ((q1.x == klo) & (q1.y == khi)) |
+                                       ((q1.z == klo) & (q1.w == khi)) | ((q2.x == klo) & (q2.y == khi)) | ((q2.z == klo) & (q2.w == khi)) |
+                                       ((q3.x == klo) & (q3.y == khi));
+                    const uint32_t hdr_hi = q3.w;
+                    const bool more = (hdr_hi >> 31) && (hop != 0u || ((hdr_hi >> idx_sig_index(key)) & 1u));
+                    sol = found;
+                    unres = !found && more;
+                }
+            } else if (need) {
+                sol = probe(p.bits, pk, k);
+            }
+            if (unres) {
+                if (p.bits)
+                    S |= 1u << W_SLOW;
+                else
+                    hop++;
+            } else {
+                hop = 0;
+                // ---- transition -------------------------------------------------------------------------------------------------
+                const uint32_t solb = sol ? 1u : 0u, above = ~((2u << cur) - 1u);
+                const uint32_t acc = (S >> W_ACC) & 15u, passm = (S >> W_PASS) & 7u;
+                const bool hit_end0 = (S >> W_HITEND) & 1u;
+                const bool accept = is_scan && (sol || !prev), trig = is_scan && !accept; // mod.rs:73, :99-102
+                // error_len (mod.rs:130-152): the first solid k-mer behind the trigger, or the end of the read
+                const bool el_found = is_errlen && !el_end && sol;
+                const bool el_done = el_end || el_found;
+                const uint32_t elen1 = is_errlen ? elen + 1u : elen; // j of this iteration
+                const uint32_t mode_new = M == BRX_GRAPH ? (uint32_t)WM_GRAPH
+                                                         : (elen1 < (uint32_t)k ? (uint32_t)WM_GRAPH : (elen1 == (uint32_t)k ? (uint32_t)WM_ONE : (uint32_t)WM_INSSUB)); // gap_size.rs:97-108
+                // a graph walk towards a k-mer that is not solid can only end in None (see above)
+                const bool el_fail = el_done && mode_new == (uint32_t)WM_GRAPH && el_end;
+                const bool to_alts = el_done && !el_fail;
+                // the candidate loop of ALTS / SCEN / MORE / WALK
+                const uint32_t cands = (is_alts ? (15u & ~(1u << c0)) : (is_scen ? 7u : (is_walk ? 15u : passm))) & above;
+                const bool s_pass = is_scen && sol && jj + 1u == c;
+                const bool s_over = is_scen && (!sol || s_pass);
+                const uint32_t acc1 = acc | ((is_alts || is_more || is_walk) ? solb << cur : 0u);
+                const uint32_t pass1 = passm | (s_pass ? 1u << cur : 0u);
+                const bool adv_c = is_alts || is_more || is_walk || s_over;
+                const bool end = adv_c && (cands == 0u || ((is_alts || is_walk) && __popc(acc1) > 1));
+                const uint32_t dm = is_scen ? pass1 : acc1;
+                const int pc = __popc(dm);
+                const uint32_t win = (uint32_t)__ffs(dm) - 1u;
+                const uint32_t smin = rem >= c + 2u ? 0u : (rem == c + 1u ? 1u : (rem == c ? 2u : 3u));
+                const bool alts_ok = end && is_alts && pc == 1;
+                const uint64_t corr_alt = (corr & ~3ull) | (uint64_t)win;
+                const bool to_scen = alts_ok && mode == (uint32_t)WM_ONE && smin < 3u;
+                // graph.rs:57-59 / gap_size.rs:52-55: path = [alt]; a corrected k-mer that already is the target is never
+                // compared with it on entry and can only be met again as a revisit: None
+                const bool to_walk = alts_ok && mode != (uint32_t)WM_ONE && !(mode == (uint32_t)WM_GRAPH && corr_alt == fc);
+                const bool to_more = end && is_scen && pc > 1;
+                const bool apply_one = end && (is_scen || is_more) && pc == 1;
+                // one walk step (graph.rs:61-82, gap_size.rs:57-85)
+                const bool step = end && is_walk && pc == 1;
+                const uint64_t nk = ((wk << 2) & mask) | (uint64_t)win;
+                bool revisit = false;
+                if (step && mode == (uint32_t)WM_INSSUB) {
+                    // viewed_kmer.contains(&corr), exactly: the k-mers met so far are corr + the first s walked bases
+                    const uint32_t t = np - 1u; // bases walked behind corr
+                    for (uint32_t sft = 0; sft <= t; sft++) {
+                        const uint64_t ks = ((corr << (2u * sft)) | (sft ? (tort >> (2u * (t - sft))) & ((1ull << (2u * sft)) - 1ull) : 0ull)) & mask;
+                        revisit |= ks == nk;
+                    }
+                }
+                const uint32_t blam1 = blam + 1u;
+                if (step && mode == (uint32_t)WM_GRAPH)
+                    revisit = nk == tort;
+                const bool step_ok = step && !revisit;
+                const bool graph_done = step_ok && mode == (uint32_t)WM_GRAPH && nk == fc;          // graph.rs:79-81
+                const bool gap_done = step_ok && mode == (uint32_t)WM_INSSUB && elen == 1u;        // (elen counts the steps left)
+                const bool too_long = step_ok && ((mode == (uint32_t)WM_INSSUB && np >= 31u) || np >= 65000u);
+                const bool walk_done = graph_done || gap_done;
+                const bool fail = el_fail || (end && is_alts && !to_scen && !to_walk) || (end && is_scen && pc == 0) ||
+                                  (end && is_more && pc != 1) || (end && is_walk && !step_ok);
+                // ---- what a successful fix writes -------------------------------------------------------------------------
+                const uint32_t used_one = 2u - win;
+                const bool jump = tgt - i > used_one + c;
+                const uint32_t cb = (cw >> (16u - 2u * (used_one + c))) & ((1u << (2u * c)) - 1u);
+                // bases of the read a walk consumes: graph.rs:84 error_len + 1; gap_size.rs:87-88 the path's own length
+                const uint32_t np1 = np + 1u;
+                const uint32_t used_walk = mode == (uint32_t)WM_GRAPH ? elen + 1u : np1;
+                const uint32_t words_fix = apply_one ? 1u : (np1 + 15u) / 16u;
+                const bool room = ne < (ecap >> 1) && (apply_one ? bw : bw0) + words_fix <= ecap && used_walk < 65536u;
+                const bool fix_one = apply_one && room, fix_walk = walk_done && room;
+                const bool give_up = ((apply_one || walk_done) && !room) || too_long;
+                // ---- the path: 2-bit codes, 16 per word, first base in the top bits ------------------------------------------
+                if (to_walk) { // path = [alt]
+                    np = 1;
+                    pacc = win;
+                    bw0 = bw;
+                }
+                if (step_ok) {
+                    pacc = (pacc << 2) | win;
+                    np = np1;
+                    if ((np1 & 15u) == 0u) {
+                        if (bw < ecap)
+                            a.BW[depth][eat + bw] = pacc;
+                        bw++;
+                    }
+                }
+                if (fix_walk || fix_one) {
+                    const uint32_t cnt = fix_one ? 1u : np;
+                    const uint32_t usd = fix_one ? used_one : used_walk;
+                    if (fix_one) {
+                        a.BW[depth][eat + bw] = (uint32_t)(corr & 3ull) << 30;
+                        bw++;
+                    } else if (np & 15u) {
+                        a.BW[depth][eat + bw] = pacc << (2u * (16u - (np & 15u)));
+                        bw++;
+                    }
+                    a.EW[depth][(eat >> 1) + ne] = make_uint2(i, (usd << 16) | cnt);
+                    ne++;
+                    ev |= 4u;
+                }
+                if (fail)
+                    bw = (is_walk || is_alts || is_errlen) ? (is_walk ? bw0 : bw) : bw; // a failed walk leaves no bases behind
+                if (give_up) { // more than a list holds / a gap the register cannot remember: back to the group kernel
+                    a.u_res[8ull * u + 6] = C_FAIL;
+                    have = false;
+                    want = true;
+                }
+                // ---- the new state ---------------------------------------------------------------------------------------------
+                const bool resolved = fail || fix_one || fix_walk;
+                const uint32_t st1 = trig ? (uint32_t)WS_ERRLEN
+                                          : (to_alts ? (uint32_t)WS_ALTS
+                                                     : (to_scen ? (uint32_t)WS_SCEN : (to_walk ? (uint32_t)WS_WALK : (to_more ? (uint32_t)WS_MORE : (resolved ? (uint32_t)WS_SCAN : st)))));
+                const uint32_t c0s = (uint32_t)(wsave >> 62); // the trigger base (ALTS starts at the first base that is not it)
+                const uint32_t cur1 = to_alts ? ((trig ? c0 : c0s) == 0u ? 1u : 0u)
+                                              : (to_scen ? smin : (to_more ? win : ((to_walk || step_ok) ? 0u : ((adv_c && !end) ? (uint32_t)__ffs(cands) - 1u : cur))));
+                const uint32_t jj1 = (is_scen && !s_over) ? jj + 1u : 0u;
+                const uint32_t accn = (to_alts || to_more || to_walk || step_ok) ? 0u : acc1, passn = to_scen ? 0u : pass1;
+                const uint32_t skipn = accept ? (skip ? skip - 1u : 0u) : ((fix_one && !jump) ? c : skip);
+                const uint32_t prevn = accept ? solb : (fail ? 0u : ((fix_one || fix_walk) ? 1u : (prev ? 1u : 0u)));
+                const uint32_t moden = el_done ? mode_new : mode;
+                const uint32_t hitn = el_done ? (el_end ? 1u : 0u) : (hit_end0 ? 1u : 0u);
+                S = st1 | (cur1 << W_CUR) | (jj1 << W_JJ) | (accn << W_ACC) | (passn << W_PASS) | (moden << W_MODE) | (hitn << W_HITEND) |
+                    (skipn << W_SKIP) | (prevn << W_PREV);
+                // Brent's tortoise (Graph) / the walked bases (GapSize's fixed-length walk)
+                if (to_walk) {
+                    tort = mode == (uint32_t)WM_GRAPH ? corr_alt : 0ull;
+                    bpow = 1;
+                    blam = 0;
+                }
+                if (step_ok) {
+                    if (mode == (uint32_t)WM_GRAPH) {
+                        const bool hop_t = blam1 == bpow;
+                        tort = hop_t ? nk : tort;
+                        bpow = hop_t ? bpow * 2u : bpow;
+                        blam = hop_t ? 0u : blam1;
+                    } else {
+                        tort = (tort << 2) | (uint64_t)win;
+                    }
+                }
+                // error_len's counter, then (GapSize's long gaps) the steps left: gap_size.rs:107, for i in 0..gap_size
+                elen = trig ? 0u : (is_errlen ? (el_done ? (mode_new == (uint32_t)WM_INSSUB ? elen1 - (uint32_t)k : elen1) : elen1)
+                                             : ((step_ok && mode == (uint32_t)WM_INSSUB) ? elen - 1u : elen));
+                fc = el_done ? (el_end ? wk : pk) : fc;
+                // the k-mers
+                const uint64_t kfix = jump ? (((corr << (2u * c)) | (uint64_t)cb) & mask) : corr;
+                kmer = accept ? pk : (fail ? ((corr & ~3ull) | (uint64_t)(trig ? c0 : c0s)) : (fix_one ? kfix : (fix_walk ? nk : kmer)));
+                wk = trig ? pk : ((is_errlen && !el_done) ? pk : (to_walk ? corr_alt : (step_ok ? nk : wk)));
+                corr = trig ? pk : (alts_ok ? corr_alt : corr);
+                ev |= trig ? 2u : 0u;
+                // ---- the window ---------------------------------------------------------------------------------------------------
+                // SCAN accepts and ERRLEN steps read on; a trigger keeps a copy of the window as it stands (at i0) and steps past
+                // the trigger base; what resolves a trigger goes back to the copy -- except a finished Graph walk, which goes on
+                // exactly where error_len stopped reading (i0 + error_len + 1)
+                if (trig) {
+                    wsave = wreg;
+                    wcnt_s = wcnt;
+                    nextw_s = nextw;
+                    pidx_s = pidx;
+                }
+                const bool back = fail || fix_one; // back to i0, then forward
+                if (back) {
+                    wreg = wsave;
+                    wcnt = wcnt_s;
+                    nextw = nextw_s;
+                    pidx = pidx_s;
+                }
+                uint32_t adv = accept ? (first ? 0u : 1u) : ((trig || (is_errlen && !el_end)) ? 1u : (fail ? 1u : (fix_one ? used_one + (jump ? c : 0u) : 0u)));
+                const uint32_t iadv = accept ? adv : (fail ? 1u : (fix_one ? adv : (fix_walk ? used_walk : 0u)));
+                i += iadv;
+                if (fix_walk && mode == (uint32_t)WM_INSSUB) {
+                    // gap_size.rs:87-88: the scan goes on at i0 + path length, which lies BEHIND what error_len read: reload
+                    const uint32_t pw = pbase + (i >> 4);
+                    wreg = (((uint64_t)a.P[pw] << 32) | a.P[pw + 1]) << ((i & 15u) * 2u);
+                    wcnt = 32u - (i & 15u);
+                    nextw = a.P[pw + 2];
+                    pidx = pw + 3u;
+                    adv = 0;
+                }
+                wreg <<= 2u * adv;
+                wcnt -= adv;
+            }
+        }
+        n_probes += (uint32_t)__builtin_popcountll(__ballot(ev & 1u));
+        n_trig += (uint32_t)__builtin_popcountll(__ballot(ev & 2u));
+        n_fix += (uint32_t)__builtin_popcountll(__ballot(ev & 4u));
+        n_miss += (uint32_t)__builtin_popcountll(__ballot(ev & 8u));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (n_rounds)
+            atomicAdd(p.ctrl + CTL_ROUNDS, (unsigned long long)n_rounds);
+        if (n_probes)
+            atomicAdd(p.ctrl + CTL_PROBES, (unsigned long long)n_probes);
+        if (n_trig)
+            atomicAdd(p.ctrl + CTL_TRIGGERS, (unsigned long long)n_trig);
+        if (n_fix)
+            atomicAdd(p.ctrl + CTL_FIXES, (unsigned long long)n_fix);
+        if (n_miss)
+            atomicAdd(p.ctrl + CTL_LANE_MISS, (unsigned long long)n_miss);
+    }
+}
+
 // ---- apply: the fixes of a read's chain of units replayed over the input -> the read's staging slot -----------------
 // Which unit's list is the truth up to where follows from the records the units left (lane 0 walks the chain); the
 // lists, concatenated, are the read's fixes in scan order, and the output is the input with them applied (mod.rs:75-102:
@@ -826,13 +1256,235 @@ __global__ __launch_bounds__(256) void lane_apply_kernel(LaneArgs a)
     }
 }
 
+// The same replay for the walking correctors' lists: a fix consumes `used` bases of the read and writes `cnt` bases that
+// sit, 16 per word, in the list of bases of its unit (a fix starts a word; the word it starts at is the running sum of the
+// words of the unit's earlier fixes, taken here from a scan over the batch).
+__global__ __launch_bounds__(256) void lane_apply_walk_kernel(LaneArgs a)
+{
+    const PassParams &p = a.p;
+    __shared__ uint32_t e_pos[AP_EDITS], e_uc[AP_EDITS], e_pi[AP_EDITS]; // position, used << 16 | cnt, piece of the fix
+    __shared__ uint32_t e_ws[AP_EDITS + 1];  // words of the batch's fixes in front of fix m
+    __shared__ uint32_t e_os[AP_EDITS + 1];  // output offset (inside the batch) of the copied stretch in front of fix m
+    __shared__ uint32_t e_in[AP_EDITS];      // input position where that stretch starts
+    __shared__ uint64_t pc_src[AP_PIECES];   // pieces: where their lists are (list index << 60 | entry of the u32 geometry)
+    __shared__ uint32_t pc_off[AP_PIECES + 1];
+    __shared__ uint32_t sh_part[4], sh_partw[4];
+    __shared__ uint32_t sh_np, sh_next_u, sh_state;
+    __shared__ uint4 sh_ra[256], sh_rb[256];
+    __shared__ uint64_t sh_eat[256];
+    for (uint32_t r = blockIdx.x; r < p.n_reads; r += gridDim.x) {
+        if (p.in_staged && p.in_lens[r] == 0xffffffffu) {
+            if (threadIdx.x == 0)
+                p.out_lens[r] = 0xffffffffu;
+            continue;
+        }
+        const uint8_t *in;
+        uint32_t n;
+        bool poisoned;
+        const uint64_t in_at = read_view(p, r, in, n, poisoned);
+        const uint64_t o0 = p.offsets[r], o1 = p.offsets[r + 1];
+        const uint64_t s0 = slot_of(o0, r, p.slack), s1 = slot_of(o1, (uint64_t)r + 1, p.slack);
+        uint8_t *dst = p.out + s0;
+        const uint64_t slot = s1 - s0;
+        const uint32_t ub = (uint32_t)a.ubase[r];
+        uint64_t total = 0;
+        uint32_t cur_in = 0;
+        bool failed = false, more = true;
+        uint32_t u_next = ub, d_next = 0;
+        __syncthreads();
+        if (ub + threadIdx.x < (uint32_t)a.ubase[r + 1]) {
+            const uint32_t uu = ub + threadIdx.x;
+            sh_ra[threadIdx.x] = *reinterpret_cast<const uint4 *>(a.u_res + 8ull * uu);
+            sh_rb[threadIdx.x] = *reinterpret_cast<const uint4 *>(a.u_res + 8ull * uu + 4);
+            const uint4 d1 = reinterpret_cast<const uint4 *>(a.u_desc + uu)[1];
+            sh_eat[threadIdx.x] = ((uint64_t)d1.w << 32) | d1.z;
+        }
+        while (more && !failed) {
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                uint32_t np = 0, cnt = 0, u = u_next, d = d_next, state = 1;
+                pc_off[0] = 0;
+                for (;;) {
+                    const bool near = u - ub < 256u;
+                    const uint4 ra = near ? sh_ra[u - ub] : *reinterpret_cast<const uint4 *>(a.u_res + 8ull * u);
+                    const uint4 rb = near ? sh_rb[u - ub] : *reinterpret_cast<const uint4 *>(a.u_res + 8ull * u + 4);
+                    const uint32_t res[8] = {ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z, rb.w};
+                    const uint32_t code = res[6];
+                    if (code >= (uint32_t)MAX_DEPTH) {
+                        state = 2;
+                        break;
+                    }
+                    bool full = false;
+                    for (; d <= code; d++) {
+                        const uint32_t ne = res[2 * d];
+                        if (ne > AP_EDITS) { // (a piece is never split over two batches here: hand the read back)
+                            state = 2;
+                            full = true;
+                            break;
+                        }
+                        if (np == AP_PIECES || cnt + ne > AP_EDITS) {
+                            full = true;
+                            break;
+                        }
+                        const uint32_t xu = d == 0 ? u : res[2 * d - 1];
+                        pc_src[np] = ((uint64_t)d << 60) | (xu - ub < 256u ? sh_eat[xu - ub] : edit_start(in_at, r, ub, xu - ub, a.u_q[xu]));
+                        cnt += ne;
+                        np++;
+                        pc_off[np] = cnt;
+                    }
+                    if (full)
+                        break;
+                    const uint32_t next = res[2 * code + 1];
+                    if (next == U_END) {
+                        state = 0;
+                        break;
+                    }
+                    u = next;
+                    d = 0;
+                }
+                sh_np = np;
+                sh_next_u = u;
+                sh_state = state | (d << 8);
+            }
+            __syncthreads();
+            const uint32_t np = sh_np;
+            u_next = sh_next_u;
+            d_next = sh_state >> 8;
+            failed = (sh_state & 0xffu) == 2u;
+            more = (sh_state & 0xffu) == 1u;
+            if (failed)
+                break;
+            const uint32_t nb = pc_off[np];
+            if (nb == 0u)
+                continue;
+            __syncthreads();
+            for (uint32_t t = threadIdx.x; t < nb; t += 256) {
+                uint32_t lo = 0, hi = np;
+                while (hi - lo > 1u) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (pc_off[mid] <= t)
+                        lo = mid;
+                    else
+                        hi = mid;
+                }
+                const uint64_t src = pc_src[lo];
+                const uint2 e = a.EW[src >> 60][((src & 0x0fffffffffffffffull) >> 1) + (t - pc_off[lo])];
+                e_pos[t] = e.x;
+                e_uc[t] = e.y;
+                e_pi[t] = lo;
+            }
+            __syncthreads();
+            const uint32_t per = (nb + 255u) / 256u;
+            const uint32_t t0 = threadIdx.x * per, t1 = t0 + per < nb ? t0 + per : nb;
+            uint32_t part = 0, partw = 0;
+            for (uint32_t t = t0; t < t1; t++) {
+                const uint32_t prev_end = t == 0 ? cur_in : e_pos[t - 1] + (e_uc[t - 1] >> 16);
+                e_in[t] = prev_end;
+                part += (e_pos[t] - prev_end) + (e_uc[t] & 0xffffu);
+                partw += ((e_uc[t] & 0xffffu) + 15u) / 16u;
+            }
+            uint32_t inc = part, incw = partw;
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t v = __shfl_up(inc, o), vw = __shfl_up(incw, o);
+                if ((int)(threadIdx.x & 63u) >= o) {
+                    inc += v;
+                    incw += vw;
+                }
+            }
+            if ((threadIdx.x & 63u) == 63u) {
+                sh_part[threadIdx.x >> 6] = inc;
+                sh_partw[threadIdx.x >> 6] = incw;
+            }
+            __syncthreads();
+            uint32_t run = inc - part, runw = incw - partw;
+            for (uint32_t q = 0; q < (threadIdx.x >> 6); q++) {
+                run += sh_part[q];
+                runw += sh_partw[q];
+            }
+            const uint32_t batch_total = sh_part[0] + sh_part[1] + sh_part[2] + sh_part[3];
+            for (uint32_t t = t0; t < t1; t++) {
+                e_os[t] = run;
+                e_ws[t] = runw;
+                run += (e_pos[t] - e_in[t]) + (e_uc[t] & 0xffffu);
+                runw += ((e_uc[t] & 0xffffu) + 15u) / 16u;
+            }
+            if (threadIdx.x == 0)
+                e_os[nb] = batch_total;
+            __syncthreads();
+            if (total + batch_total <= slot) {
+                uint8_t *ob = dst + total;
+                const uint32_t head = (uint32_t)((16u - (uint32_t)((uintptr_t)ob & 15u)) & 15u);
+                const uint32_t n_chunks = (batch_total + 31u) / 16u + 1u;
+                for (uint32_t ch = threadIdx.x; ch < n_chunks; ch += 256) {
+                    const uint32_t x0 = ch == 0 ? 0u : head + 16u * (ch - 1u);
+                    uint32_t x1 = ch == 0 ? head : x0 + 16u;
+                    if (x1 > batch_total)
+                        x1 = batch_total;
+                    if (x0 >= x1)
+                        continue;
+                    uint32_t lo = 0, hi = nb;
+                    while (hi - lo > 1u) {
+                        const uint32_t mid = (lo + hi) >> 1;
+                        if (e_os[mid] <= x0)
+                            lo = mid;
+                        else
+                            hi = mid;
+                    }
+                    uint32_t m = lo;
+                    const uint32_t copied_end = e_os[m + 1] - (e_uc[m] & 0xffffu); // the fix's own bases start here
+                    if (x1 - x0 == 16u && x1 <= copied_end) {
+                        uint4 q;
+                        __builtin_memcpy(&q, in + e_in[m] + (x0 - e_os[m]), 16);
+                        *reinterpret_cast<uint4 *>(ob + x0) = q;
+                    } else {
+                        for (uint32_t x = x0; x < x1; x++) {
+                            while (x >= e_os[m + 1])
+                                m++;
+                            const uint32_t rel = x - e_os[m], seglen = e_pos[m] - e_in[m];
+                            if (rel < seglen) {
+                                ob[x] = in[e_in[m] + rel];
+                            } else {
+                                const uint32_t tb = rel - seglen; // base tb of the fix
+                                const uint64_t src = pc_src[e_pi[m]];
+                                const uint32_t first_fix = pc_off[e_pi[m]];
+                                const uint32_t w = a.BW[src >> 60][(src & 0x0fffffffffffffffull) + (e_ws[m] - e_ws[first_fix]) + (tb >> 4)];
+                                ob[x] = bit2nuc((w >> (30u - 2u * (tb & 15u))) & 3u);
+                            }
+                        }
+                    }
+                }
+            }
+            total += batch_total;
+            cur_in = e_pos[nb - 1] + (e_uc[nb - 1] >> 16);
+        }
+        if (!failed && n > cur_in) {
+            const uint32_t len = n - cur_in;
+            if (total + len <= slot)
+                copy_bytes(dst + total, in + cur_in, len);
+            total += len;
+        }
+        if (threadIdx.x == 0) {
+            if (failed) {
+                const unsigned long long at = atomicAdd(p.ctrl + CTL_LANE_FAIL, 1ull);
+                a.fail_list[at] = r;
+            } else if (total + 1u > slot) {
+                p.out_lens[r] = 0xffffffffu;
+                atomicAdd(p.ctrl + CTL_OVERFLOW, 1ull);
+            } else {
+                p.out_lens[r] = (uint32_t)total;
+            }
+        }
+    }
+}
+
 struct LaneWork {
     uint32_t *nu = nullptr, *u_read = nullptr, *u_q = nullptr, *u_res = nullptr, *fail_list = nullptr, *P = nullptr;
     UnitDesc *u_desc = nullptr;
     uint4 *u_in = nullptr;
     uint32_t *E[MAX_DEPTH] = {nullptr, nullptr, nullptr};
+    uint32_t *BW[MAX_DEPTH] = {nullptr, nullptr, nullptr};
     uint64_t *ubase = nullptr, *u_qk = nullptr;
-    uint64_t reads_cap = 0, units_cap = 0, p_cap = 0, e_cap = 0;
+    uint64_t reads_cap = 0, units_cap = 0, p_cap = 0, e_cap = 0, bw_cap = 0;
 };
 
 int grow_dev(void **ptr, uint64_t bytes)
@@ -852,6 +1504,17 @@ uint32_t env_u32(const char *name, uint32_t dflt)
 {
     const char *e = getenv(name); // (read per call: the fuzzers sweep these)
     return e && *e ? (uint32_t)strtoul(e, nullptr, 10) : dflt;
+}
+
+template <bool IDX, int M>
+void launch_lane_walk(const LaneArgs &a, uint32_t blocks, hipStream_t s)
+{
+    if (a.p.k == 19)
+        lane_walk_kernel<IDX, 19, M><<<blocks, 256, 0, s>>>(a);
+    else if (a.p.k == 21)
+        lane_walk_kernel<IDX, 21, M><<<blocks, 256, 0, s>>>(a);
+    else
+        lane_walk_kernel<IDX, 0, M><<<blocks, 256, 0, s>>>(a);
 }
 
 template <bool IDX>
@@ -875,7 +1538,8 @@ void lane_ws_free(brx_chain *ch)
     if (!w)
         return;
     for (void *q : {(void *)w->u_in, (void *)w->u_desc, (void *)w->nu, (void *)w->u_read, (void *)w->u_q, (void *)w->u_res, (void *)w->fail_list, (void *)w->P,
-                    (void *)w->E[0], (void *)w->E[1], (void *)w->E[2], (void *)w->ubase, (void *)w->u_qk})
+                    (void *)w->E[0], (void *)w->E[1], (void *)w->E[2], (void *)w->BW[0], (void *)w->BW[1], (void *)w->BW[2], (void *)w->ubase,
+                    (void *)w->u_qk})
         if (q)
             (void)hipFree(q);
     delete w;
@@ -885,7 +1549,12 @@ void lane_ws_free(brx_chain *ch)
 int lane_pass(brx_chain *ch, const PassParams &p, const LanePassInfo &info, hipStream_t s)
 {
     // BRX_LANE=0: the group kernel only.  The window of a round shows 8 bases: look-aheads up to off + c + 1 <= 8.
-    if (env_u32("BRX_LANE", 1u) == 0u || p.flip || p.c < 1 || p.c > 5 || p.k > 31 || p.n_reads == 0)
+    const bool walk = info.method != BRX_ONE;
+    if (env_u32("BRX_LANE", 1u) == 0u || p.flip || p.k > 31 || p.n_reads == 0)
+        return BRX_ERR_UNSUPPORTED;
+    if (info.method != BRX_GRAPH && (p.c < 1 || p.c > 5)) // (Graph has no look-aheads; One and GapSize's One branch do)
+        return BRX_ERR_UNSUPPORTED;
+    if (walk && env_u32("BRX_LANE_WALK", 1u) == 0u)
         return BRX_ERR_UNSUPPORTED;
     const bool idx = p.idx.lines != nullptr;
     if (!idx && !p.bits)
@@ -946,6 +1615,12 @@ int lane_pass(brx_chain *ch, const PassParams &p, const LanePassInfo &info, hipS
             BRX_TRY(grow_dev((void **)&w->E[d], cap * 4));
         w->e_cap = cap;
     }
+    if (walk && w->bw_cap < e_bound) {
+        const uint64_t cap = e_bound + e_bound / 16;
+        for (int d = 0; d < MAX_DEPTH; d++)
+            BRX_TRY(grow_dev((void **)&w->BW[d], cap * 4));
+        w->bw_cap = cap;
+    }
     if (scan_tmp_bytes(p.n_reads) > ch->scan_tmp_cap) {
         set_error("lane pass: scan scratch smaller than the batch");
         return BRX_ERR_ARG;
@@ -963,8 +1638,13 @@ int lane_pass(brx_chain *ch, const PassParams &p, const LanePassInfo &info, hipS
     a.u_desc = w->u_desc;
     a.u_in = w->u_in;
     a.P = w->P;
-    for (int d = 0; d < MAX_DEPTH; d++)
+    for (int d = 0; d < MAX_DEPTH; d++) {
         a.E[d] = w->E[d];
+        a.EW[d] = reinterpret_cast<uint2 *>(w->E[d]); // (8-byte entries at half the index: the same bytes)
+        a.BW[d] = w->BW[d];
+    }
+    if (info.method == BRX_GRAPH)
+        a.p.c = 1; // (unused by Graph; keeps the One branch's shifts in range)
     a.fail_list = w->fail_list;
 
     const uint32_t rb = (p.n_reads + 255u) / 256u;
@@ -988,18 +1668,35 @@ int lane_pass(brx_chain *ch, const PassParams &p, const LanePassInfo &info, hipS
         lane_link_kernel<<<(uint32_t)(lb < 4096ull ? lb : 4096ull), 256, 0, s>>>(a);
     }
     {
-        KernelTimer t("correct_pass", s);
+        static const char *names[5] = {"correct_pass", "correct_pass_two", "correct_pass_graph", "correct_pass_greedy", "correct_pass_gap_size"};
+        KernelTimer t(names[info.method], s);
         const uint64_t want = (units_bound + 255ull) / 256ull;
-        const uint32_t blocks = (uint32_t)(want < 256ull * BRX_LANE_WAVES ? want : 256ull * BRX_LANE_WAVES);
-        if (idx)
-            launch_lane<true>(a, blocks, s);
-        else
-            launch_lane<false>(a, blocks, s);
+        const uint64_t waves = walk ? BRX_WALK_WAVES : BRX_LANE_WAVES;
+        const uint32_t blocks = (uint32_t)(want < 256ull * waves ? want : 256ull * waves);
+        if (info.method == BRX_ONE) {
+            if (idx)
+                launch_lane<true>(a, blocks, s);
+            else
+                launch_lane<false>(a, blocks, s);
+        } else if (info.method == BRX_GRAPH) {
+            if (idx)
+                launch_lane_walk<true, BRX_GRAPH>(a, blocks, s);
+            else
+                launch_lane_walk<false, BRX_GRAPH>(a, blocks, s);
+        } else {
+            if (idx)
+                launch_lane_walk<true, BRX_GAP_SIZE>(a, blocks, s);
+            else
+                launch_lane_walk<false, BRX_GAP_SIZE>(a, blocks, s);
+        }
     }
     {
         KernelTimer t("lane_apply", s);
         const uint32_t grid = p.n_reads < (1u << 16) ? p.n_reads : (1u << 16);
-        lane_apply_kernel<<<grid, 256, 0, s>>>(a);
+        if (walk)
+            lane_apply_walk_kernel<<<grid, 256, 0, s>>>(a);
+        else
+            lane_apply_kernel<<<grid, 256, 0, s>>>(a);
     }
     {
         // the reads the units could not settle (three misses in a row, more fixes than a list holds): the group kernel
@@ -1008,7 +1705,10 @@ int lane_pass(brx_chain *ch, const PassParams &p, const LanePassInfo &info, hipS
         q.only = w->fail_list;
         q.only_n = p.ctrl + CTL_LANE_FAIL;
         BRX_HIP(hipMemsetAsync(p.ctrl + CTL_WORK, 0, 8, s));
-        BRX_TRY(launch_one_list(q, s));
+        if (walk)
+            BRX_TRY(launch_walk_list(q, info.method, s));
+        else
+            BRX_TRY(launch_one_list(q, s));
     }
     BRX_HIP(hipGetLastError());
     return BRX_OK;

@@ -121,3 +121,56 @@ def test_growing_reads_and_slot_overflow(lane_env):
     om = O.build_methods(ref, ["one"], 2, 7)
     assert got == [O.correct_record(om, r, True) for r in reads]
     assert sum(len(x) for x in got) > sum(len(r) for r in reads)
+
+
+# ---------------------------------------------------------------- Graph / GapSize in lane form ----------------
+@pytest.mark.parametrize("chunk,sync", [(64, 1), (100, 4), (333, 2), (None, None)])
+@pytest.mark.parametrize("names", [["graph"], ["gap_size"], ["one", "graph", "gap_size"]])
+def test_walking_correctors_any_chunking(raw_reads, solid_fixture_bytes, lane_env, chunk, sync, names):
+    """correct::Graph / correct::GapSize forward passes as lane automata (error_len, alt_nucs, the unique-successor walk
+    with Brent's detector / the exact visited rule, GapSize's three-way dispatch): raw.fasta against the reference's
+    fixture set, forward only and forward + reverse, any chunk length / sync rule"""
+    lane_env(chunk, sync)
+    reads = raw_reads[:50]
+    gs = br_amd.Pcon.from_pcon_solid(solid_fixture_bytes)
+    ref = O.Solid.from_bytes(solid_fixture_bytes)
+    om = O.build_methods(ref, names, 5, 7)
+    for two_side in (True, False):
+        chain = br_amd.Chain(gs, [(m, 5, 7) for m in names], two_side=two_side)
+        got = chain.correct_reads(reads)
+        bad = [i for i, (r, x) in enumerate(zip(reads, got)) if x != O.correct_record(om, r, two_side)]
+        assert not bad, bad[:10]
+        st = chain.last_stats()
+        assert st["lane_units"] >= len(reads) and st["fixes"] > 0
+
+
+def test_walk_lane_off_is_the_group_kernel(raw_reads, solid_fixture_bytes, monkeypatch):
+    gs = br_amd.Pcon.from_pcon_solid(solid_fixture_bytes)
+    monkeypatch.setenv("BRX_LANE_WALK", "0")
+    chain = br_amd.Chain(gs, [("graph", 5, 7), ("gap_size", 5, 7)], two_side=False)
+    a = chain.correct_reads(raw_reads[:25])
+    assert chain.last_stats()["lane_units"] == 0
+    monkeypatch.delenv("BRX_LANE_WALK")
+    chain2 = br_amd.Chain(gs, [("graph", 5, 7), ("gap_size", 5, 7)], two_side=False)
+    b = chain2.correct_reads(raw_reads[:25])
+    assert chain2.last_stats()["lane_units"] > 0 and a == b
+
+
+@pytest.mark.parametrize("k,method", [(13, "graph"), (13, "gap_size"), (19, "graph"), (19, "gap_size"), (21, "graph"), (21, "gap_size")])
+def test_walking_correctors_synthetic(lane_env, k, method):
+    """the bench's error model against counted sets: bit vector (k = 13), lazy bits + index (19), sparse chained index (21)"""
+    lane_env(128, 3)
+    cfg = synth.config(genome_len=40_000, read_len=3_000)
+    g = synth.genome_host(cfg)
+    bases, offs = synth.reads_host(cfg, g, 0, 400)
+    reads = [bases[int(offs[i]):int(offs[i + 1])].tobytes() for i in range(400)]
+    reads += [b"", b"ACGT", reads[0][:k - 1], reads[1][:k], reads[2][:k + 1], reads[3][:k + 7], reads[4][:130]]
+    gs = br_amd.Pcon.from_count(reads, k, 2)
+    ref = O.Solid.from_count(k, O.count_reads(k, reads), 2) if k <= 15 else O.Solid.sparse_from_count(k, reads, 2)
+    chain = br_amd.Chain(gs, [(method, 5, 7)], two_side=False)
+    got = chain.correct_reads(reads)
+    om = O.build_methods(ref, [method], 5, 7)
+    bad = [i for i, (r, x) in enumerate(zip(reads, got)) if x != O.correct_record(om, r, False)]
+    assert not bad, bad[:10]
+    st = chain.last_stats()
+    assert st["lane_units"] > 4_000 and st["fixes"] > 1_000

@@ -75,7 +75,7 @@ while time.time() < t_end:
            "BRX_HASH_FINAL": str(rng.choice(["", "", "0"])),
            # One's forward pass cut into units (brx_onelane.hip): off, tiny chunks, sync runs from sloppy to strict
            "BRX_LANE": str(rng.choice(["", "", "", "0"])), "BRX_LANE_CHUNK": str(rng.choice(["", "64", "100", "333"])),
-           "BRX_LANE_SYNC": str(rng.choice(["", "1", "2", "8"]))}
+           "BRX_LANE_SYNC": str(rng.choice(["", "1", "2", "8"])), "BRX_LANE_WALK": str(rng.choice(["", "", "", "0"]))}
     for key, v in env.items():
         if v == "":
             os.environ.pop(key, None)
