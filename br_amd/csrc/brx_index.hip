@@ -193,6 +193,7 @@ static int index_build_locked(brx_set *set, const uint64_t *d_keys, uint64_t n, 
         return BRX_ERR_NOMEM;
     }
     set->idx_valid = false;
+    set->idx_gen++;
     const uint64_t n_lines = 1ull << log_lines;
     if (set->lines_alloc < n_lines) {
         if (set->d_lines)
@@ -244,6 +245,7 @@ static int index_build_locked(brx_set *set, const uint64_t *d_keys, uint64_t n, 
     set->idx_open = false;
     set->idx_linebits = true; // this build filled the occupancy bits behind the lines
     set->idx_valid = true;
+    set->idx_gen++;
     return BRX_OK;
 }
 
@@ -336,6 +338,7 @@ int index_insert_reads(brx_set *set, const uint8_t *d_bases, const uint64_t *d_o
     set->idx_linebits = false; // filled k-mer by k-mer: no occupancy bits
     set->idx_open = true;
     set->idx_valid = true;
+    set->idx_gen++;
     set->keylist_valid = false; // the table is the set now
     return BRX_OK;
 }
@@ -472,6 +475,7 @@ int brx_set_index_drop(brx_set_t *set)
         return BRX_ERR_ARG;
     std::lock_guard<std::mutex> g(set->idx_mu);
     set->idx_valid = false;
+    set->idx_gen++;
     if (set->d_lines && use_device(set->device) == BRX_OK)
         (void)hipFree(set->d_lines);
     set->d_lines = nullptr;

@@ -84,6 +84,13 @@ struct brx_set {
     uint32_t idx_m;
     bool idx_valid;
     bool idx_declined;       // index_ensure looked at the set and found an index would not help
+    // successor table beside the index (brx_onelane.hip): per line, one byte per slot -- for either orientation of the
+    // slot's k-mer, whether it has exactly one solid successor and which.  Built on first use by a walking corrector,
+    // stale whenever the index changes (idx_gen counts the changes).
+    uint64_t *d_succ = nullptr;
+    uint64_t succ_lines = 0;     // lines the table was allocated for
+    uint64_t succ_gen = ~0ull;   // idx_gen it was built at
+    uint64_t idx_gen = 0;
     uint64_t idx_keys, idx_overflow_keys;
     // solid hashes of the current bits, when the builder produced them on the side (partitioned finish)
     uint64_t *d_keylist;

@@ -77,6 +77,7 @@ struct LaneArgs {
     uint2 *EW[MAX_DEPTH];      // the walking correctors' lists: pos, consumed << 16 | bases written (same memory as E)
     uint32_t *BW[MAX_DEPTH];   // ... and the written bases, 16 per word, a fix starting a word
     uint32_t *fail_list;       // reads handed back to the group kernel     [n_reads]
+    const uint64_t *succ;      // per index line, a byte per slot: the unique solid successor of either orientation (or null)
 };
 
 // byte offset of read r's input in its buffer, its length (0 for a poisoned read)
@@ -616,6 +617,43 @@ __device__ __forceinline__ void copy_bytes(uint8_t *dst, const uint8_t *src, uin
         dst[j] = src[j];
 }
 
+// ---- successor table: next_nucs (mod.rs:118-128) of every indexed k-mer, worked out once --------------------------------
+// A walk step asks for the FOUR successors of a solid k-mer (graph.rs:62, gap_size.rs:58) -- four rounds of a lane.  Which
+// of them are solid is a property of the set alone, so it is tabulated beside the index: one byte per slot of every line,
+// bits 0-2 for the slot's canonical k-mer as it is stored, bits 4-6 for its reverse complement: 4 | base if exactly one
+// of add(x, 0..3) is solid, else 0.  A walk then needs ONE probe per step: find the slot of its k-mer, read the byte.
+// k-mers that live outside the lines (turned away by a full line into the bit vector) have no byte: their steps are
+// asked the long way.
+__global__ __launch_bounds__(256) void succ_build_kernel(PassParams p, uint64_t n_lines, uint64_t *__restrict__ succ)
+{
+    const int k = p.k;
+    const uint64_t mask = kmask(k);
+    for (uint64_t line = (uint64_t)blockIdx.x * 256ull + threadIdx.x; line < n_lines; line += (uint64_t)gridDim.x * 256ull) {
+        uint64_t out = 0;
+        if (!p.idx.line_bits || ((p.idx.line_bits[line >> 5] >> (line & 31u)) & 1u)) {
+            const uint64_t *L = p.idx.lines + line * 8ull;
+            for (int sl = 0; sl < IDX_SLOTS; sl++) {
+                const uint64_t v = L[sl];
+                if (!v)
+                    continue;
+                const uint64_t half = (v - 1ull) << 1;                       // canonical >> 1, back in place
+                const uint64_t cano = half | (uint64_t)(popc64(half) & 1);   // the even-popcount member (brx_kmer.hpp)
+                uint32_t byte = 0;
+                for (int o = 0; o < 2; o++) {
+                    const uint64_t x = o ? revcomp(cano, k) : cano;
+                    uint32_t m4 = 0;
+                    for (uint64_t b = 0; b < 4; b++)
+                        m4 |= (set_get<true>(p, add_nuc(x, b, mask), k) ? 1u : 0u) << b;
+                    if (__popc(m4) == 1)
+                        byte |= (4u | ((uint32_t)__ffs(m4) - 1u)) << (4 * o);
+                }
+                out |= (uint64_t)byte << (8 * sl);
+            }
+        }
+        succ[line] = out;
+    }
+}
+
 // ---- the automaton for the walking correctors: correct::Graph and correct::GapSize -----------------------------------
 // Reference: Graph::correct_error (src/correct/graph.rs:44-85), error_len / alt_nucs / next_nucs (src/correct/mod.rs:
 // 114-152), GapSize::correct_error and ins_sub_correction (src/correct/gap_size.rs:44-108; its `one` branch is
@@ -638,14 +676,14 @@ __device__ __forceinline__ void copy_bytes(uint8_t *dst, const uint8_t *src, uin
 // register and every earlier k-mer is rebuilt from them for the comparison; longer gaps go back to the group kernel.
 // What a fix writes: an entry (position, bases of the read consumed, bases written) and the written bases, 16 per word.
 enum { W_ST = 0, W_CUR = 3, W_JJ = 5, W_ACC = 8, W_PASS = 12, W_MODE = 15, W_HITEND = 17, W_SKIP = 24, W_PREV = 27, W_FIRST = 28, W_SLOW = 29 };
-enum { WS_SCAN = 0, WS_ALTS = 1, WS_SCEN = 2, WS_MORE = 3, WS_ERRLEN = 4, WS_WALK = 5 };
+enum { WS_SCAN = 0, WS_ALTS = 1, WS_SCEN = 2, WS_MORE = 3, WS_ERRLEN = 4, WS_WALK = 5, WS_WALK4 = 6 };
 enum { WM_GRAPH = 0, WM_ONE = 1, WM_INSSUB = 2 };
-#ifndef BRX_WALK_WAVES
-#define BRX_WALK_WAVES 4
-#endif
+// waves per SIMD the walking automata are compiled for: Graph needs 89 registers, GapSize (its One branch and the exact
+// visited rule on top) more than the 102 of five waves
+constexpr int walk_waves(int method) { return method == BRX_GRAPH ? 5 : 4; }
 
 template <bool IDX, int KT, int M>
-__global__ __launch_bounds__(256, BRX_WALK_WAVES) void lane_walk_kernel(LaneArgs a)
+__global__ __launch_bounds__(256, walk_waves(M)) void lane_walk_kernel(LaneArgs a)
 {
     const PassParams &p = a.p;
     const int k = KT ? KT : p.k;
@@ -664,6 +702,7 @@ __global__ __launch_bounds__(256, BRX_WALK_WAVES) void lane_walk_kernel(LaneArgs
     uint32_t wcnt = 0, nextw = 0, pidx = 0, wcnt_s = 0, nextw_s = 0, pidx_s = 0, pbase = 0;
     uint64_t kmer = 0, corr = 0, wk = 0, fc = 0, tort = 0; // tort: Brent's tortoise (Graph) / the walked bases (GapSize)
     uint32_t S = 0, hop = 0, cline = 0xffffffffu;
+    uint64_t csucc = 0; // the successor bytes of the line held in LDS
     uint32_t elen = 0, bpow = 1, blam = 0, np = 0, pacc = 0;
     uint32_t n_rounds = 0, n_probes = 0, n_trig = 0, n_fix = 0, n_miss = 0;
     uint32_t wnext = 0, wend = 0;
@@ -784,10 +823,11 @@ __global__ __launch_bounds__(256, BRX_WALK_WAVES) void lane_walk_kernel(LaneArgs
                 pidx++;
             }
             const uint32_t st = S & 7u, cur = (S >> W_CUR) & 3u, jj = (S >> W_JJ) & 7u, skip = (S >> W_SKIP) & 7u;
-            const uint32_t mode = (S >> W_MODE) & 3u;
+            // (Graph knows its mode at compile time: the One branch and the fixed-length walk fall out of its kernel)
+            const uint32_t mode = M == BRX_GRAPH ? (uint32_t)WM_GRAPH : ((S >> W_MODE) & 3u);
             const bool prev = (S >> W_PREV) & 1u, first = (S >> W_FIRST) & 1u, slow = (S >> W_SLOW) & 1u;
             const bool is_scan = st == WS_SCAN, is_alts = st == WS_ALTS, is_scen = st == WS_SCEN, is_more = st == WS_MORE,
-                       is_errlen = st == WS_ERRLEN, is_walk = st == WS_WALK;
+                       is_errlen = st == WS_ERRLEN, is_wfast = st == WS_WALK, is_walk = st == WS_WALK4;
             // SCAN and ERRLEN read the window where it is; everything else looks at the bases from the trigger on
             const bool live = is_scan || is_errlen;
             const uint32_t cw = (uint32_t)((live ? wreg : wsave) >> 48);
@@ -799,7 +839,7 @@ __global__ __launch_bounds__(256, BRX_WALK_WAVES) void lane_walk_kernel(LaneArgs
             const uint32_t nb = (is_scan ? (first ? 0u : 1u) : (is_errlen ? 1u : (is_scen ? jj + 1u : (is_more ? c + 1u : 0u))));
             const uint32_t b0 = (is_scen || is_more) ? off : 0u;
             const uint32_t wbits = (cw >> (16u - 2u * (b0 + nb))) & ((1u << (2u * nb)) - 1u);
-            const uint64_t base_k = is_scan ? kmer : ((is_errlen || is_walk) ? wk : corr);
+            const uint64_t base_k = is_scan ? kmer : ((is_errlen || is_walk || is_wfast) ? wk : corr);
             uint64_t pk = ((base_k << (2u * nb)) | (uint64_t)wbits) & mask;
             pk = is_alts ? ((pk & ~3ull) | (uint64_t)cur) : (is_walk ? (((pk << 2) & mask) | (uint64_t)cur) : pk);
             // error_len stops without a probe where the read ends (mod.rs:137-139)
@@ -809,6 +849,7 @@ __global__ __launch_bounds__(256, BRX_WALK_WAVES) void lane_walk_kernel(LaneArgs
 
             // ---- KmerSet::get -------------------------------------------------------------------------------------------
             bool sol = is_scan && !need, unres = false;
+            uint32_t slot = 7u; // the slot of the line the k-mer was found in (7: not in a line's slot)
             if (IDX) {
                 uint64_t key;
                 const uint32_t home = index_locate(p.idx, pk, k, key);
@@ -820,6 +861,8 @@ __global__ __launch_bounds__(256, BRX_WALK_WAVES) void lane_walk_kernel(LaneArgs
                     for (int e = 0; e < 4; e++)
                         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(L + 16 * e),
                                                          (__attribute__((address_space(3))) void *)&lc[e][wb], 16, 0, 0);
+                    if (a.succ)
+                        csucc = a.succ[line];
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     cline = line;
                 }
@@ -829,9 +872,11 @@ __global__ __launch_bounds__(256, BRX_WALK_WAVES) void lane_walk_kernel(LaneArgs
                 } else if (need) {
                     const uint4 q0 = lc[0][tid], q1 = lc[1][tid], q2 = lc[2][tid], q3 = lc[3][tid];
                     const uint32_t klo = (uint32_t)key, khi = (uint32_t)(key >> 32);
-                    const bool found = ((q0.x == klo) & (q0.y == khi)) | ((q0.z == klo) & (q0.w == khi)) | ((q1.x == klo) & (q1.y == khi)) |
-                                       ((q1.z == klo) & (q1.w == khi)) | ((q2.x == klo) & (q2.y == khi)) | ((q2.z == klo) & (q2.w == khi)) |
-                                       ((q3.x == klo) & (q3.y == khi));
+                    const bool f0 = (q0.x == klo) & (q0.y == khi), f1 = (q0.z == klo) & (q0.w == khi), f2 = (q1.x == klo) & (q1.y == khi),
+                               f3 = (q1.z == klo) & (q1.w == khi), f4 = (q2.x == klo) & (q2.y == khi), f5 = (q2.z == klo) & (q2.w == khi),
+                               f6 = (q3.x == klo) & (q3.y == khi);
+                    const bool found = f0 | f1 | f2 | f3 | f4 | f5 | f6;
+                    slot = f0 ? 0u : (f1 ? 1u : (f2 ? 2u : (f3 ? 3u : (f4 ? 4u : (f5 ? 5u : (f6 ? 6u : 7u))))));
                     const uint32_t hdr_hi = q3.w;
                     const bool more = (hdr_hi >> 31) && (hop != 0u || ((hdr_hi >> idx_sig_index(key)) & 1u));
                     sol = found;
@@ -862,6 +907,12 @@ __global__ __launch_bounds__(256, BRX_WALK_WAVES) void lane_walk_kernel(LaneArgs
                 const bool el_fail = el_done && mode_new == (uint32_t)WM_GRAPH && el_end;
                 const bool to_alts = el_done && !el_fail;
                 // the candidate loop of ALTS / SCEN / MORE / WALK
+                // WALK, the short way: the k-mer's own byte of the successor table says whether exactly one successor is solid
+                // and which; a k-mer found outside the lines' slots (or no table) asks the four successors one by one (WALK4)
+                const uint32_t sb = (uint32_t)(csucc >> (8u * slot + ((popc64(wk) & 1) ? 4u : 0u))) & 7u;
+                const bool wf_known = is_wfast && a.succ != nullptr && slot < 7u;
+                const bool wf_step = wf_known && (sb & 4u) != 0u, wf_dead = wf_known && (sb & 4u) == 0u;
+                const bool to_walk4 = is_wfast && !wf_known;
                 const uint32_t cands = (is_alts ? (15u & ~(1u << c0)) : (is_scen ? 7u : (is_walk ? 15u : passm))) & above;
                 const bool s_pass = is_scen && sol && jj + 1u == c;
                 const bool s_over = is_scen && (!sol || s_pass);
@@ -871,7 +922,7 @@ __global__ __launch_bounds__(256, BRX_WALK_WAVES) void lane_walk_kernel(LaneArgs
                 const bool end = adv_c && (cands == 0u || ((is_alts || is_walk) && __popc(acc1) > 1));
                 const uint32_t dm = is_scen ? pass1 : acc1;
                 const int pc = __popc(dm);
-                const uint32_t win = (uint32_t)__ffs(dm) - 1u;
+                const uint32_t win = wf_step ? (sb & 3u) : (uint32_t)__ffs(dm) - 1u;
                 const uint32_t smin = rem >= c + 2u ? 0u : (rem == c + 1u ? 1u : (rem == c ? 2u : 3u));
                 const bool alts_ok = end && is_alts && pc == 1;
                 const uint64_t corr_alt = (corr & ~3ull) | (uint64_t)win;
@@ -882,7 +933,7 @@ __global__ __launch_bounds__(256, BRX_WALK_WAVES) void lane_walk_kernel(LaneArgs
                 const bool to_more = end && is_scen && pc > 1;
                 const bool apply_one = end && (is_scen || is_more) && pc == 1;
                 // one walk step (graph.rs:61-82, gap_size.rs:57-85)
-                const bool step = end && is_walk && pc == 1;
+                const bool step = (end && is_walk && pc == 1) || wf_step;
                 const uint64_t nk = ((wk << 2) & mask) | (uint64_t)win;
                 bool revisit = false;
                 if (step && mode == (uint32_t)WM_INSSUB) {
@@ -902,7 +953,7 @@ __global__ __launch_bounds__(256, BRX_WALK_WAVES) void lane_walk_kernel(LaneArgs
                 const bool too_long = step_ok && ((mode == (uint32_t)WM_INSSUB && np >= 31u) || np >= 65000u);
                 const bool walk_done = graph_done || gap_done;
                 const bool fail = el_fail || (end && is_alts && !to_scen && !to_walk) || (end && is_scen && pc == 0) ||
-                                  (end && is_more && pc != 1) || (end && is_walk && !step_ok);
+                                  (end && is_more && pc != 1) || (end && is_walk && !step_ok) || wf_dead || (wf_step && !step_ok);
                 // ---- what a successful fix writes -------------------------------------------------------------------------
                 const uint32_t used_one = 2u - win;
                 const bool jump = tgt - i > used_one + c;
@@ -943,8 +994,8 @@ __global__ __launch_bounds__(256, BRX_WALK_WAVES) void lane_walk_kernel(LaneArgs
                     ne++;
                     ev |= 4u;
                 }
-                if (fail)
-                    bw = (is_walk || is_alts || is_errlen) ? (is_walk ? bw0 : bw) : bw; // a failed walk leaves no bases behind
+                if (fail && (is_walk || is_wfast))
+                    bw = bw0; // a failed walk leaves no bases behind
                 if (give_up) { // more than a list holds / a gap the register cannot remember: back to the group kernel
                     a.u_res[8ull * u + 6] = C_FAIL;
                     have = false;
@@ -954,12 +1005,15 @@ __global__ __launch_bounds__(256, BRX_WALK_WAVES) void lane_walk_kernel(LaneArgs
                 const bool resolved = fail || fix_one || fix_walk;
                 const uint32_t st1 = trig ? (uint32_t)WS_ERRLEN
                                           : (to_alts ? (uint32_t)WS_ALTS
-                                                     : (to_scen ? (uint32_t)WS_SCEN : (to_walk ? (uint32_t)WS_WALK : (to_more ? (uint32_t)WS_MORE : (resolved ? (uint32_t)WS_SCAN : st)))));
+                                                     : (to_scen ? (uint32_t)WS_SCEN
+                                                                : (to_more ? (uint32_t)WS_MORE
+                                                                           : (resolved ? (uint32_t)WS_SCAN
+                                                                                       : (to_walk4 ? (uint32_t)WS_WALK4 : ((to_walk || step_ok) ? (uint32_t)WS_WALK : st))))));
                 const uint32_t c0s = (uint32_t)(wsave >> 62); // the trigger base (ALTS starts at the first base that is not it)
                 const uint32_t cur1 = to_alts ? ((trig ? c0 : c0s) == 0u ? 1u : 0u)
-                                              : (to_scen ? smin : (to_more ? win : ((to_walk || step_ok) ? 0u : ((adv_c && !end) ? (uint32_t)__ffs(cands) - 1u : cur))));
+                                              : (to_scen ? smin : (to_more ? win : ((to_walk || step_ok || to_walk4) ? 0u : ((adv_c && !end) ? (uint32_t)__ffs(cands) - 1u : cur))));
                 const uint32_t jj1 = (is_scen && !s_over) ? jj + 1u : 0u;
-                const uint32_t accn = (to_alts || to_more || to_walk || step_ok) ? 0u : acc1, passn = to_scen ? 0u : pass1;
+                const uint32_t accn = (to_alts || to_more || to_walk || step_ok || to_walk4) ? 0u : acc1, passn = to_scen ? 0u : pass1;
                 const uint32_t skipn = accept ? (skip ? skip - 1u : 0u) : ((fix_one && !jump) ? c : skip);
                 const uint32_t prevn = accept ? solb : (fail ? 0u : ((fix_one || fix_walk) ? 1u : (prev ? 1u : 0u)));
                 const uint32_t moden = el_done ? mode_new : mode;
@@ -1646,6 +1700,30 @@ int lane_pass(brx_chain *ch, const PassParams &p, const LanePassInfo &info, hipS
     if (info.method == BRX_GRAPH)
         a.p.c = 1; // (unused by Graph; keeps the One branch's shifts in range)
     a.fail_list = w->fail_list;
+    a.succ = nullptr;
+    if (walk && idx && env_u32("BRX_LANE_SUCC", 1u) != 0u) {
+        // the successor table of the set's index: built the first time a walking corrector runs on it, again when the
+        // index has changed since
+        brx_set *set = const_cast<brx_set *>(ch->set);
+        std::lock_guard<std::mutex> g(set->idx_mu);
+        const uint64_t n_lines = 1ull << (32u - p.idx.line_shift);
+        if (!set->d_succ || set->succ_lines != n_lines || set->succ_gen != set->idx_gen) {
+            if (set->d_succ && set->succ_lines != n_lines) {
+                (void)hipFree(set->d_succ);
+                set->d_succ = nullptr;
+            }
+            if (!set->d_succ) {
+                BRX_TRY(grow_dev((void **)&set->d_succ, n_lines * 8ull));
+                set->succ_lines = n_lines;
+            }
+            KernelTimer t("succ_build", s);
+            const uint64_t blocks = (n_lines + 255ull) / 256ull;
+            succ_build_kernel<<<(uint32_t)(blocks < 65536ull ? blocks : 65536ull), 256, 0, s>>>(p, n_lines, set->d_succ);
+            BRX_HIP(hipGetLastError());
+            set->succ_gen = set->idx_gen;
+        }
+        a.succ = set->d_succ;
+    }
 
     const uint32_t rb = (p.n_reads + 255u) / 256u;
     {
@@ -1671,7 +1749,7 @@ int lane_pass(brx_chain *ch, const PassParams &p, const LanePassInfo &info, hipS
         static const char *names[5] = {"correct_pass", "correct_pass_two", "correct_pass_graph", "correct_pass_greedy", "correct_pass_gap_size"};
         KernelTimer t(names[info.method], s);
         const uint64_t want = (units_bound + 255ull) / 256ull;
-        const uint64_t waves = walk ? BRX_WALK_WAVES : BRX_LANE_WAVES;
+        const uint64_t waves = walk ? (uint64_t)walk_waves(info.method) : (uint64_t)BRX_LANE_WAVES;
         const uint32_t blocks = (uint32_t)(want < 256ull * waves ? want : 256ull * waves);
         if (info.method == BRX_ONE) {
             if (idx)

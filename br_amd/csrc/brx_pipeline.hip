@@ -70,19 +70,21 @@ struct Pinned {
         uint64_t want = cap ? cap : (1u << 20);
         while (want < need)
             want += want / 2 + (1u << 20);
-        uint8_t *q = nullptr;
+        // from the library's pool of page-locked blocks (brx_api.hip): hipHostMalloc costs milliseconds per block, and a
+        // job is two pipeline runs (count, then correct) -- or many, when a host calls them file after file -- that want the
+        // same handful of sizes
         const double t0 = now_s();
-        hipError_t e = hipHostMalloc((void **)&q, want, hipHostMallocDefault);
+        uint8_t *q = (uint8_t *)host_buf_acquire(want);
         if (pipe_trace())
-            fprintf(stderr, "[brx pipe] hipHostMalloc %.1f MB: %.2f ms\n", (double)want / 1e6, (now_s() - t0) * 1e3);
-        if (e != hipSuccess) {
-            set_error("hipHostMalloc(%llu B): %s", (unsigned long long)want, hipGetErrorString(e));
+            fprintf(stderr, "[brx pipe] page-locked block %.1f MB: %.2f ms\n", (double)want / 1e6, (now_s() - t0) * 1e3);
+        if (!q) {
+            set_error("page-locked host block of %llu B: out of memory", (unsigned long long)want);
             return BRX_ERR_NOMEM;
         }
         if (p) {
             if (keep)
                 memcpy(q, p, keep);
-            (void)hipHostFree(p);
+            host_buf_release(p);
         }
         p = q;
         cap = want;
@@ -91,7 +93,7 @@ struct Pinned {
     ~Pinned()
     {
         if (p)
-            (void)hipHostFree(p);
+            host_buf_release(p);
     }
 };
 

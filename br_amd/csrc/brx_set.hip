@@ -651,6 +651,8 @@ void brx_set_free(brx_set_t *set)
             (void)hipFree(set->d_keylist);
         if (set->d_keylist_n)
             (void)hipFree(set->d_keylist_n);
+        if (set->d_succ)
+            (void)hipFree(set->d_succ);
     }
     delete set;
 }
