@@ -54,6 +54,9 @@ constexpr uint32_t C_FAIL = 0xfffffff1u;   // res[6]: three misses in a row, or 
 constexpr uint32_t C_VOID = 0xfffffff2u;   // res[6]: nothing produced
 constexpr int MAX_DEPTH = 3;               // edit lists: own stretch + two stretches scanned after a miss
 constexpr uint32_t MAX_LANE_READ = 1u << 28; // positions are kept in 28 bits of an edit
+constexpr uint32_t AP_EDITS = 1024; // fixes replayed per batch
+constexpr uint32_t AP_PIECES = 256; // pieces (unit, depth) gathered per batch
+constexpr uint32_t AP_VERIFY = 1024; // longest fixed-length walk whose k-mers the replay kernel checks for a repeat
 constexpr uint32_t LANE_GRAB = 64;           // units a wave draws from the global counter at a time
 #ifndef BRX_LANE_WAVES
 #define BRX_LANE_WAVES 7 // waves per SIMD the automaton is compiled for (tools/ab_build.sh sweeps it)
@@ -680,7 +683,7 @@ enum { WS_SCAN = 0, WS_ALTS = 1, WS_SCEN = 2, WS_MORE = 3, WS_ERRLEN = 4, WS_WAL
 enum { WM_GRAPH = 0, WM_ONE = 1, WM_INSSUB = 2 };
 // waves per SIMD the walking automata are compiled for: Graph needs 89 registers, GapSize (its One branch and the exact
 // visited rule on top) more than the 102 of five waves
-constexpr int walk_waves(int method) { return method == BRX_GRAPH ? 5 : 4; }
+constexpr int walk_waves(int) { return 5; }
 
 template <bool IDX, int KT, int M>
 __global__ __launch_bounds__(256, walk_waves(M)) void lane_walk_kernel(LaneArgs a)
@@ -935,22 +938,18 @@ __global__ __launch_bounds__(256, walk_waves(M)) void lane_walk_kernel(LaneArgs 
                 // one walk step (graph.rs:61-82, gap_size.rs:57-85)
                 const bool step = (end && is_walk && pc == 1) || wf_step;
                 const uint64_t nk = ((wk << 2) & mask) | (uint64_t)win;
+                // GapSize's fixed-length walk (gap_size.rs:57-85) is not checked for revisits HERE: it ends after `gap` steps
+                // whatever it meets, a walk that would have been cut short by its visited set either fails later anyway (None
+                // both ways) or comes out with a repeated k-mer in its path -- which the replay kernel finds (every such fix
+                // is marked and carries its first k-mer), handing the read back to the group kernel
                 bool revisit = false;
-                if (step && mode == (uint32_t)WM_INSSUB) {
-                    // viewed_kmer.contains(&corr), exactly: the k-mers met so far are corr + the first s walked bases
-                    const uint32_t t = np - 1u; // bases walked behind corr
-                    for (uint32_t sft = 0; sft <= t; sft++) {
-                        const uint64_t ks = ((corr << (2u * sft)) | (sft ? (tort >> (2u * (t - sft))) & ((1ull << (2u * sft)) - 1ull) : 0ull)) & mask;
-                        revisit |= ks == nk;
-                    }
-                }
                 const uint32_t blam1 = blam + 1u;
                 if (step && mode == (uint32_t)WM_GRAPH)
                     revisit = nk == tort;
                 const bool step_ok = step && !revisit;
                 const bool graph_done = step_ok && mode == (uint32_t)WM_GRAPH && nk == fc;          // graph.rs:79-81
                 const bool gap_done = step_ok && mode == (uint32_t)WM_INSSUB && elen == 1u;        // (elen counts the steps left)
-                const bool too_long = step_ok && ((mode == (uint32_t)WM_INSSUB && np >= 31u) || np >= 65000u);
+                const bool too_long = step_ok && ((mode == (uint32_t)WM_INSSUB && np >= AP_VERIFY - 1u) || np >= 65000u);
                 const bool walk_done = graph_done || gap_done;
                 const bool fail = el_fail || (end && is_alts && !to_scen && !to_walk) || (end && is_scen && pc == 0) ||
                                   (end && is_more && pc != 1) || (end && is_walk && !step_ok) || wf_dead || (wf_step && !step_ok);
@@ -961,7 +960,7 @@ __global__ __launch_bounds__(256, walk_waves(M)) void lane_walk_kernel(LaneArgs 
                 // bases of the read a walk consumes: graph.rs:84 error_len + 1; gap_size.rs:87-88 the path's own length
                 const uint32_t np1 = np + 1u;
                 const uint32_t used_walk = mode == (uint32_t)WM_GRAPH ? elen + 1u : np1;
-                const uint32_t words_fix = apply_one ? 1u : (np1 + 15u) / 16u;
+                const uint32_t words_fix = apply_one ? 1u : (np1 + 15u) / 16u + (mode == (uint32_t)WM_INSSUB ? 2u : 0u);
                 const bool room = ne < (ecap >> 1) && (apply_one ? bw : bw0) + words_fix <= ecap && used_walk < 65536u;
                 const bool fix_one = apply_one && room, fix_walk = walk_done && room;
                 const bool give_up = ((apply_one || walk_done) && !room) || too_long;
@@ -970,6 +969,13 @@ __global__ __launch_bounds__(256, walk_waves(M)) void lane_walk_kernel(LaneArgs 
                     np = 1;
                     pacc = win;
                     bw0 = bw;
+                    if (mode == (uint32_t)WM_INSSUB) { // the first k-mer of the path, for the replay kernel's check
+                        if (bw + 2u <= ecap) {
+                            a.BW[depth][eat + bw] = (uint32_t)corr_alt;
+                            a.BW[depth][eat + bw + 1u] = (uint32_t)(corr_alt >> 32);
+                        }
+                        bw += 2u;
+                    }
                 }
                 if (step_ok) {
                     pacc = (pacc << 2) | win;
@@ -990,7 +996,7 @@ __global__ __launch_bounds__(256, walk_waves(M)) void lane_walk_kernel(LaneArgs 
                         a.BW[depth][eat + bw] = pacc << (2u * (16u - (np & 15u)));
                         bw++;
                     }
-                    a.EW[depth][(eat >> 1) + ne] = make_uint2(i, (usd << 16) | cnt);
+                    a.EW[depth][(eat >> 1) + ne] = make_uint2(i | ((fix_walk && mode == (uint32_t)WM_INSSUB) ? 0x80000000u : 0u), (usd << 16) | cnt);
                     ne++;
                     ev |= 4u;
                 }
@@ -1032,8 +1038,6 @@ __global__ __launch_bounds__(256, walk_waves(M)) void lane_walk_kernel(LaneArgs 
                         tort = hop_t ? nk : tort;
                         bpow = hop_t ? bpow * 2u : bpow;
                         blam = hop_t ? 0u : blam1;
-                    } else {
-                        tort = (tort << 2) | (uint64_t)win;
                     }
                 }
                 // error_len's counter, then (GapSize's long gaps) the steps left: gap_size.rs:107, for i in 0..gap_size
@@ -1104,8 +1108,6 @@ __global__ __launch_bounds__(256, walk_waves(M)) void lane_walk_kernel(LaneArgs 
 // a fix writes one base and consumes `used` bases of the read; everything else is copied through).  Copying is
 // OUTPUT-centric: every thread produces 16 aligned output bytes, finds the fix its first byte lies behind by bisection
 // of the fixes' output offsets (LDS), and in the common case -- no fix inside its 16 bytes -- moves them as one vector.
-constexpr uint32_t AP_EDITS = 1024; // fixes replayed per batch
-constexpr uint32_t AP_PIECES = 256; // pieces (unit, depth) gathered per batch
 
 __global__ __launch_bounds__(256) void lane_apply_kernel(LaneArgs a)
 {
@@ -1326,6 +1328,10 @@ __global__ __launch_bounds__(256) void lane_apply_walk_kernel(LaneArgs a)
     __shared__ uint32_t sh_np, sh_next_u, sh_state;
     __shared__ uint4 sh_ra[256], sh_rb[256];
     __shared__ uint64_t sh_eat[256];
+    __shared__ uint64_t vk[AP_VERIFY];            // the k-mers of a fixed-length walk being checked for a repeat
+    __shared__ uint32_t vw[AP_VERIFY / 16 + 4];   // ... its first k-mer and its bases
+    const int k_ = p.k;
+    const uint64_t kmask_ = kmask(k_);
     for (uint32_t r = blockIdx.x; r < p.n_reads; r += gridDim.x) {
         if (p.in_staged && p.in_lens[r] == 0xffffffffu) {
             if (threadIdx.x == 0)
@@ -1423,7 +1429,7 @@ __global__ __launch_bounds__(256) void lane_apply_walk_kernel(LaneArgs a)
                 }
                 const uint64_t src = pc_src[lo];
                 const uint2 e = a.EW[src >> 60][((src & 0x0fffffffffffffffull) >> 1) + (t - pc_off[lo])];
-                e_pos[t] = e.x;
+                e_pos[t] = e.x; // (bit 31: a fixed-length walk, to be checked for a repeated k-mer below)
                 e_uc[t] = e.y;
                 e_pi[t] = lo;
             }
@@ -1432,10 +1438,10 @@ __global__ __launch_bounds__(256) void lane_apply_walk_kernel(LaneArgs a)
             const uint32_t t0 = threadIdx.x * per, t1 = t0 + per < nb ? t0 + per : nb;
             uint32_t part = 0, partw = 0;
             for (uint32_t t = t0; t < t1; t++) {
-                const uint32_t prev_end = t == 0 ? cur_in : e_pos[t - 1] + (e_uc[t - 1] >> 16);
+                const uint32_t prev_end = t == 0 ? cur_in : (e_pos[t - 1] & 0x7fffffffu) + (e_uc[t - 1] >> 16);
                 e_in[t] = prev_end;
-                part += (e_pos[t] - prev_end) + (e_uc[t] & 0xffffu);
-                partw += ((e_uc[t] & 0xffffu) + 15u) / 16u;
+                part += ((e_pos[t] & 0x7fffffffu) - prev_end) + (e_uc[t] & 0xffffu);
+                partw += ((e_uc[t] & 0xffffu) + 15u) / 16u + ((e_pos[t] >> 31) ? 2u : 0u);
             }
             uint32_t inc = part, incw = partw;
             for (int o = 1; o < 64; o <<= 1) {
@@ -1459,12 +1465,48 @@ __global__ __launch_bounds__(256) void lane_apply_walk_kernel(LaneArgs a)
             for (uint32_t t = t0; t < t1; t++) {
                 e_os[t] = run;
                 e_ws[t] = runw;
-                run += (e_pos[t] - e_in[t]) + (e_uc[t] & 0xffffu);
-                runw += ((e_uc[t] & 0xffffu) + 15u) / 16u;
+                run += ((e_pos[t] & 0x7fffffffu) - e_in[t]) + (e_uc[t] & 0xffffu);
+                runw += ((e_uc[t] & 0xffffu) + 15u) / 16u + ((e_pos[t] >> 31) ? 2u : 0u);
             }
             if (threadIdx.x == 0)
                 e_os[nb] = batch_total;
             __syncthreads();
+            // GapSize's fixed-length walks (gap_size.rs:57-85) were not checked for revisits by the lanes: the reference returns
+            // None the moment a k-mer of the walk repeats (viewed_kmer, :75-81).  A fix whose gap + 1 k-mers -- its first one
+            // and one more per walked base -- hold a repeat would not have been made: the read goes back to the group kernel.
+            for (uint32_t m = 0; m < nb && !failed; m++) {
+                if (!(e_pos[m] >> 31))
+                    continue;
+                const uint32_t cnt = e_uc[m] & 0xffffu;
+                if (cnt > AP_VERIFY) {
+                    failed = true;
+                    break;
+                }
+                const uint64_t src = pc_src[e_pi[m]];
+                const uint32_t *W = a.BW[src >> 60] + (src & 0x0fffffffffffffffull) + (e_ws[m] - e_ws[pc_off[e_pi[m]]]);
+                const uint32_t nwords = (cnt + 15u) / 16u + 2u;
+                __syncthreads();
+                for (uint32_t t = threadIdx.x; t < nwords; t += 256)
+                    vw[t] = W[t];
+                __syncthreads();
+                const uint64_t first_k = ((uint64_t)vw[1] << 32) | vw[0];
+                for (uint32_t sidx = threadIdx.x; sidx < cnt; sidx += 256) {
+                    // the k-mer after sidx walked bases (base 0 of the fix is the last base of first_k itself)
+                    uint64_t km = sidx < (uint32_t)k_ ? first_k : 0ull;
+                    for (uint32_t j = sidx < (uint32_t)k_ ? 1u : sidx - (uint32_t)k_ + 1u; j <= sidx; j++)
+                        km = ((km << 2) | ((vw[2u + (j >> 4)] >> (30u - 2u * (j & 15u))) & 3u)) & kmask_;
+                    vk[sidx] = km;
+                }
+                __syncthreads();
+                int dup = 0;
+                for (uint32_t sidx = threadIdx.x; sidx < cnt; sidx += 256)
+                    for (uint32_t t2 = sidx + 1u; t2 < cnt; t2++)
+                        dup |= vk[sidx] == vk[t2];
+                if (__syncthreads_or(dup))
+                    failed = true;
+            }
+            if (failed)
+                break;
             if (total + batch_total <= slot) {
                 uint8_t *ob = dst + total;
                 const uint32_t head = (uint32_t)((16u - (uint32_t)((uintptr_t)ob & 15u)) & 15u);
@@ -1494,14 +1536,14 @@ __global__ __launch_bounds__(256) void lane_apply_walk_kernel(LaneArgs a)
                         for (uint32_t x = x0; x < x1; x++) {
                             while (x >= e_os[m + 1])
                                 m++;
-                            const uint32_t rel = x - e_os[m], seglen = e_pos[m] - e_in[m];
+                            const uint32_t rel = x - e_os[m], seglen = (e_pos[m] & 0x7fffffffu) - e_in[m];
                             if (rel < seglen) {
                                 ob[x] = in[e_in[m] + rel];
                             } else {
                                 const uint32_t tb = rel - seglen; // base tb of the fix
                                 const uint64_t src = pc_src[e_pi[m]];
                                 const uint32_t first_fix = pc_off[e_pi[m]];
-                                const uint32_t w = a.BW[src >> 60][(src & 0x0fffffffffffffffull) + (e_ws[m] - e_ws[first_fix]) + (tb >> 4)];
+                                const uint32_t w = a.BW[src >> 60][(src & 0x0fffffffffffffffull) + (e_ws[m] - e_ws[first_fix]) + ((e_pos[m] >> 31) ? 2u : 0u) + (tb >> 4)];
                                 ob[x] = bit2nuc((w >> (30u - 2u * (tb & 15u))) & 3u);
                             }
                         }
@@ -1509,7 +1551,7 @@ __global__ __launch_bounds__(256) void lane_apply_walk_kernel(LaneArgs a)
                 }
             }
             total += batch_total;
-            cur_in = e_pos[nb - 1] + (e_uc[nb - 1] >> 16);
+            cur_in = (e_pos[nb - 1] & 0x7fffffffu) + (e_uc[nb - 1] >> 16);
         }
         if (!failed && n > cur_in) {
             const uint32_t len = n - cur_in;

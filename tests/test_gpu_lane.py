@@ -173,4 +173,38 @@ def test_walking_correctors_synthetic(lane_env, k, method):
     bad = [i for i, (r, x) in enumerate(zip(reads, got)) if x != O.correct_record(om, r, False)]
     assert not bad, bad[:10]
     st = chain.last_stats()
-    assert st["lane_units"] > 4_000 and st["fixes"] > 1_000
+    assert st["lane_units"] > 4_000 and st["fixes"] > 1_000 and st["lane_redone_reads"] < 40
+
+
+def test_gap_size_walks_over_repeats(lane_env):
+    """GapSize's fixed-length walk returns None when it meets a k-mer twice (gap_size.rs:75-81).  The lanes do not look;
+    the replay kernel does, for every such fix -- tandem repeats longer than k make walks go round in circles here."""
+    lane_env(64, 1)
+    rng = np.random.default_rng(11)
+    k = 9
+    alpha = np.frombuffer(b"ACGT", dtype=np.uint8)
+    unit = rng.choice(alpha, 14).tobytes()
+    genome = rng.choice(alpha, 300).tobytes() + unit * 30 + rng.choice(alpha, 300).tobytes() + unit * 12 + rng.choice(alpha, 200).tobytes()
+    reads = []
+    for _ in range(300):
+        s = int(rng.integers(0, len(genome) - 400))
+        r = bytearray(genome[s:s + 400])
+        for pos in sorted(rng.integers(15, len(r) - 15, size=int(rng.integers(2, 14))).tolist(), reverse=True):
+            x = rng.random()
+            if x < 0.4:
+                del r[pos]
+            elif x < 0.7:
+                r.insert(pos, int(alpha[rng.integers(0, 4)]))
+            else:
+                r[pos] = int(alpha[rng.integers(0, 4)])
+        reads.append(bytes(r))
+    gs = br_amd.Pcon.from_fasta([genome], k)
+    ref = O.Solid(k)
+    ref.set_seq(genome)
+    for names in (["gap_size"], ["graph"], ["gap_size", "graph"]):
+        chain = br_amd.Chain(gs, [(m, 2, 7) for m in names], two_side=True)
+        got = chain.correct_reads(reads)
+        om = O.build_methods(ref, names, 2, 7)
+        bad = [i for i, (r, x) in enumerate(zip(reads, got)) if x != O.correct_record(om, r, True)]
+        assert not bad, (names, bad[:10])
+        assert chain.last_stats()["lane_units"] > 0

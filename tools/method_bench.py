@@ -40,7 +40,8 @@ for m in methods:
         wall = (time.perf_counter() - t0) * 1e3
         best = wall if best is None else min(best, wall)
     st = chain.last_stats()
-    row = {"method": m, "wall_ms_fwd_rev": round(best, 2), "gbases_per_s": round(total / best / 1e6, 3), "out_bases": int(out_total),
+    prof = {kk: round(v["total_ms"], 2) for kk, v in _lib.profile_all().items() if v["launches"]}
+    row = {"kernels_ms": prof, "method": m, "wall_ms_fwd_rev": round(best, 2), "gbases_per_s": round(total / best / 1e6, 3), "out_bases": int(out_total),
            **{kk: int(v) for kk, v in st.items()}}
     rows.append(row)
     print(json.dumps(row), flush=True)
