@@ -44,6 +44,10 @@ namespace {
 constexpr int F_BITS = 12;      // hashes per fine bucket = 4096 (8 KiB of u16 counters per wave)
 constexpr int MAX_LEVELS = 4;
 constexpr int MAX_DIGIT_BITS = 9;
+// (the scans below keep per-thread partial sums in fixed-size arrays: ln_colscan_kernel tot[2] / run[2] covers 512 digits
+// with 256 threads, col_scan_digits_kernel one wave's 16 digits per lane covers 1024; col_scan_columns_kernel v[8] covers
+// 2048 chunks, which part_add_batch guarantees by doubling the chunk length)
+static_assert(MAX_DIGIT_BITS <= 9, "the digit scans of the partition passes are written for at most 512 digits");
 
 struct Plan {
     int k, nbits, nlev;

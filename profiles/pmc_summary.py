@@ -61,11 +61,18 @@ res = {"tag": tag, "calibration": {"random_4B_load_bytes_as_counted": cal_rand,
                                    "stream_fraction_counted": cal_stream}, "bases_per_launch": bases, "kernels": summary}
 with open(os.path.join(here, f"{tag}_pmc_summary.json"), "w") as f:
     json.dump(res, f, indent=1)
-# correct_pass = every one_kernel<G, K> / correct_kernel<G, M> instance (forward G=8 and reverse G=64 launches): launch-weighted mean
-ck = [v for k, v in summary.items() if k.startswith("correct_kernel<") or k.startswith("one_kernel<")]
+# correct_pass = the scan passes of the step: the reverse pass is one launch (one_kernel<64, K> / correct_kernel<64, M>), the
+# forward pass in lane form is several (lane_kernel / lane_walk_kernel and its helpers: unit tables + packed copy, sync
+# points, link, the replay of the fixes, the few reads handed back to the group kernel); bytes of all of them / passes
+PASS_MAIN = ("correct_kernel<", "one_kernel<", "lane_kernel<", "lane_walk_kernel<")
+PASS_AUX = ("lane_units_kernel", "lane_pack_kernel", "lane_sync_kernel", "lane_link_kernel", "lane_apply_kernel", "lane_apply_walk_kernel",
+            "succ_build_kernel")
+ck = [v for k, v in summary.items() if k.startswith(PASS_MAIN)]
+aux = [v for k, v in summary.items() if k.startswith(PASS_AUX)]
 if ck and bases:
-    n_launch = sum(v["launches"] for v in ck)
-    per_launch = sum(v["hbm_bytes_per_launch"] * v["launches"] for v in ck) / n_launch
+    # passes = launches of the main kernels, not counting the list-mode re-runs (a handful of reads: <..., true> instances)
+    n_launch = sum(v["launches"] for k, v in summary.items() if k.startswith(PASS_MAIN) and ", true>" not in k)
+    per_launch = sum(v["hbm_bytes_per_launch"] * v["launches"] for v in ck + aux) / n_launch
     with open(os.path.join(here, "traffic_latest.json"), "w") as f:
         json.dump({"kernel": "correct_pass", "bases_per_launch": bases, "hbm_bytes_per_launch": per_launch,
                    "launches_averaged": n_launch,

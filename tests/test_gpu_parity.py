@@ -432,6 +432,7 @@ def test_walk_list_overflow_retry(raw_reads, solid_fixture_bytes, monkeypatch, r
     with the reverse pass."""
     monkeypatch.setenv("BRX_MAXPATH", "2")
     monkeypatch.setenv("BRX_REDO_MAX", redo_max)
+    monkeypatch.setenv("BRX_LANE_WALK", "0")   # (the visited lists are the group kernel's; the lane form keeps none)
     ref = O.Solid.from_bytes(solid_fixture_bytes)
     gs = br_amd.Pcon.from_pcon_solid(solid_fixture_bytes)
     reads = raw_reads[:24] + [b"", b"ACGT"]
