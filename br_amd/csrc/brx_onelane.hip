@@ -1705,6 +1705,13 @@ int lane_pass(brx_chain *ch, const PassParams &p, const LanePassInfo &info, hipS
         return BRX_ERR_UNSUPPORTED;
     if (walk && env_u32("BRX_LANE_WALK", 1u) == 0u)
         return BRX_ERR_UNSUPPORTED;
+    // One against a LARGE index stays with the group kernel: every lane of a wave probes a line of a different read, 64
+    // unrelated pages per load, and past 2^26 lines (4 GiB) that costs more than the lanes save -- same box, correction of
+    // 2 / 3.5 / 6.25 Gbp against sets of 41 / 73 / 130 M k-mers (2^26 / 2^27 / 2^28 lines): lanes 56.6 / 132.5 / 256 ms,
+    // groups 61.0 / 107.9 / 197 ms.  (The walking methods gain at 2^28 lines all the same: their group kernels are
+    // latency-bound, BASELINE configs[4]'s share 5.1 -> 6.9 Gbases/s.)
+    if (!walk && p.idx.lines && 32u - p.idx.line_shift > env_u32("BRX_LANE_MAX_LOG_LINES", 26u))
+        return BRX_ERR_UNSUPPORTED;
     const bool idx = p.idx.lines != nullptr;
     if (!idx && !p.bits)
         return BRX_ERR_UNSUPPORTED;
