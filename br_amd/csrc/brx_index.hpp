@@ -67,6 +67,58 @@ __device__ __forceinline__ uint32_t minimizer_hash_w(uint64_t fwd, uint64_t rc, 
     return best;
 }
 
+__device__ __forceinline__ uint32_t minimizer_of(uint64_t fwd, uint64_t rc, uint32_t m, uint32_t w);
+// the same, also giving the minimum over all windows but the OLDEST one (the m-mer at the front of the k-mer): the k-mer
+// that follows in a read shares exactly those W - 1 windows, so its minimizer is min(excl_oldest, hash of its one new
+// m-mer) -- brx_onelane.hip asks about two consecutive positions per round that way
+template <int W>
+__device__ __forceinline__ uint32_t minimizer_hash_w2(uint64_t fwd, uint64_t rc, uint32_t mm, uint32_t &excl_oldest)
+{
+    const uint32_t flo = (uint32_t)fwd, fhi = (uint32_t)(fwd >> 32), rlo = (uint32_t)rc, rhi = (uint32_t)(rc >> 32);
+    uint32_t best = 0xffffffffu;
+#pragma unroll
+    for (int j = 0; j < W - 1; j++) {
+        const uint32_t f = __builtin_amdgcn_alignbit(fhi, flo, 2 * j) & mm;
+        const uint32_t r = __builtin_amdgcn_alignbit(rhi, rlo, 2 * (W - 1 - j)) & mm;
+        const uint32_t c = f < r ? f : r;
+        const uint32_t h = c * 0x9E3779B1u;
+        best = h < best ? h : best;
+    }
+    excl_oldest = best;
+    const uint32_t f = __builtin_amdgcn_alignbit(fhi, flo, 2 * (W - 1)) & mm;
+    const uint32_t r = rlo & mm;
+    const uint32_t c = f < r ? f : r;
+    const uint32_t h = c * 0x9E3779B1u;
+    return h < best ? h : best;
+}
+
+// false: more than 16 windows (no two-position rounds there)
+__device__ __forceinline__ bool minimizer_pair(uint64_t fwd, uint64_t rc, uint32_t m, uint32_t w, uint32_t &best, uint32_t &excl_oldest)
+{
+    const uint32_t mm = m >= 16u ? 0xffffffffu : (1u << (2u * m)) - 1u;
+    switch (w) { // wave-uniform
+    case 2: best = minimizer_hash_w2<2>(fwd, rc, mm, excl_oldest); return true;
+    case 3: best = minimizer_hash_w2<3>(fwd, rc, mm, excl_oldest); return true;
+    case 4: best = minimizer_hash_w2<4>(fwd, rc, mm, excl_oldest); return true;
+    case 5: best = minimizer_hash_w2<5>(fwd, rc, mm, excl_oldest); return true;
+    case 6: best = minimizer_hash_w2<6>(fwd, rc, mm, excl_oldest); return true;
+    case 7: best = minimizer_hash_w2<7>(fwd, rc, mm, excl_oldest); return true;
+    case 8: best = minimizer_hash_w2<8>(fwd, rc, mm, excl_oldest); return true;
+    case 9: best = minimizer_hash_w2<9>(fwd, rc, mm, excl_oldest); return true;
+    case 10: best = minimizer_hash_w2<10>(fwd, rc, mm, excl_oldest); return true;
+    case 11: best = minimizer_hash_w2<11>(fwd, rc, mm, excl_oldest); return true;
+    case 12: best = minimizer_hash_w2<12>(fwd, rc, mm, excl_oldest); return true;
+    case 13: best = minimizer_hash_w2<13>(fwd, rc, mm, excl_oldest); return true;
+    case 14: best = minimizer_hash_w2<14>(fwd, rc, mm, excl_oldest); return true;
+    case 15: best = minimizer_hash_w2<15>(fwd, rc, mm, excl_oldest); return true;
+    case 16: best = minimizer_hash_w2<16>(fwd, rc, mm, excl_oldest); return true;
+    default:
+        best = minimizer_of(fwd, rc, m, w);
+        excl_oldest = 0;
+        return false;
+    }
+}
+
 __device__ __forceinline__ uint32_t minimizer_of(uint64_t fwd, uint64_t rc, uint32_t m, uint32_t w)
 {
     const uint32_t mm = m >= 16u ? 0xffffffffu : (1u << (2u * m)) - 1u;

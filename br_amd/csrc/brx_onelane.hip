@@ -475,10 +475,31 @@ __global__ __launch_bounds__(256, BRX_LANE_WAVES) void lane_kernel(LaneArgs a)
 
             // ---- KmerSet::get -------------------------------------------------------------------------------------------
             bool sol = is0 && !need, unres = false;
+            // SCAN asks about TWO positions when it can: add(pk, seq[i+1]) shares its reverse complement and all but one of its
+            // minimizer windows with pk, and two k-mers in three share their index line -- then the second answer comes out
+            // of the line already in hand, and a round moves the scan two bases.  Not across the unit's target, not behind a
+            // fix (skip), not when the second k-mer lives in another line: the next round asks about it then, as before.
+            bool two = false, sol2 = false;
+            uint64_t pk2 = 0;
+            const uint32_t c1 = (cw >> 12) & 3u; // seq[i + 1]
             if (IDX) {
-                uint64_t key;
-                const uint32_t home = index_locate(p.idx, pk, k, key);
+                const uint64_t rc = revcomp(pk, k);
+                const uint64_t key = (((popc64(pk) & 1) ? rc : pk) >> 1) + 1ull;
+                uint32_t best, best_excl;
+                const bool pairable = minimizer_pair(pk, rc, p.idx.m, p.idx.w, best, best_excl);
+                const uint32_t home = index_line_of(best, p.idx.line_shift);
                 const uint32_t line = (home + hop) & (0xffffffffu >> p.idx.line_shift);
+                pk2 = ((pk << 2) | (uint64_t)c1) & mask;
+                const uint64_t rc2 = (rc >> 2) | ((uint64_t)(c1 ^ 2u) << (2 * k - 2));
+                const uint64_t key2 = (((popc64(pk2) & 1) ? rc2 : pk2) >> 1) + 1ull;
+                uint32_t home2;
+                {
+                    const uint32_t mm = p.idx.m >= 16u ? 0xffffffffu : (1u << (2u * p.idx.m)) - 1u;
+                    const uint32_t f2 = (uint32_t)pk2 & mm, r2 = (uint32_t)(rc2 >> (2u * (p.idx.w - 1u))) & mm;
+                    const uint32_t h2 = (f2 < r2 ? f2 : r2) * 0x9E3779B1u;
+                    home2 = index_line_of(h2 < best_excl ? h2 : best_excl, p.idx.line_shift);
+                }
+                two = pairable && is0 && !first && need && skip == 0u && !slow && hop == 0u && home2 == home && tgt - i >= 2u && rem >= 2u;
                 if (need && !slow && line != cline) { // not the line this lane holds: fetch it, keep it
                     // straight from global memory into LDS (global_load_lds_dwordx4: lane l of the wave writes at the
                     // wave-uniform base + 16 l, lanes switched off write nothing: tools/lds_dma_test.hip): no registers
@@ -507,10 +528,21 @@ __global__ __launch_bounds__(256, BRX_LANE_WAVES) void lane_kernel(LaneArgs a)
                     const bool more = (hdr_hi >> 31) && (hop != 0u || ((hdr_hi >> idx_sig_index(key)) & 1u));
                     sol = found;
                     unres = !found && more;
+                    // the second position, against the same line
+                    const uint32_t k2lo = (uint32_t)key2, k2hi = (uint32_t)(key2 >> 32);
+                    const bool found2 = ((q0.x == k2lo) & (q0.y == k2hi)) | ((q0.z == k2lo) & (q0.w == k2hi)) | ((q1.x == k2lo) & (q1.y == k2hi)) |
+                                        ((q1.z == k2lo) & (q1.w == k2hi)) | ((q2.x == k2lo) & (q2.y == k2hi)) | ((q2.z == k2lo) & (q2.w == k2hi)) |
+                                        ((q3.x == k2lo) & (q3.y == k2hi));
+                    const bool more2 = (hdr_hi >> 31) && ((hdr_hi >> idx_sig_index(key2)) & 1u);
+                    sol2 = found2;
+                    two = two && !(!found2 && more2); // (a flagged line that may have turned the second k-mer away: ask next round)
+                } else {
+                    two = false;
                 }
             } else if (need) {
                 sol = probe(p.bits, pk, k);
             }
+            ev |= (two && !unres) ? 16u : 0u;
             if (unres) {
                 // ask again next round: the bit vector, or (sparse sets) the next line of the chain
                 if (p.bits)
@@ -526,7 +558,11 @@ __global__ __launch_bounds__(256, BRX_LANE_WAVES) void lane_kernel(LaneArgs a)
                 // scenarios that scored c (exist/mod.rs:138-147) -- with one result mask, and one verdict when they run out.
                 const uint32_t solb = sol ? 1u : 0u, above = ~((2u << cur) - 1u);
                 const uint32_t acc = (S >> S_ACC) & 15u, passm = (S >> S_PASS) & 7u;
-                const bool accept = is0 && (sol || !prev), trig = is0 && !accept; // mod.rs:73, :99-102 (:67 for `first`)
+                const bool accept = is0 && (sol || !prev), trigA = is0 && !accept; // mod.rs:73, :99-102 (:67 for `first`)
+                // the second position: `previous` is the first one's answer by then
+                const bool acceptB = accept && two && (sol2 || !sol), trigB = accept && two && !(sol2 || !sol);
+                const bool trig = trigA || trigB;
+                const uint32_t ctrig = trigB ? c1 : c0; // the trigger base: ALTS starts at the first base that is not it
                 const uint32_t cands = (is1 ? (15u & ~(1u << c0)) : (is2 ? 7u : passm)) & above;
                 const bool s_pass = is2 && sol && jj + 1u == c;  // get_score == c
                 const bool s_over = is2 && (!sol || s_pass);     // ... or it stops below c (exist/mod.rs:38-42)
@@ -553,18 +589,18 @@ __global__ __launch_bounds__(256, BRX_LANE_WAVES) void lane_kernel(LaneArgs a)
                 const bool fix = apply_b && room;
                 // the new state word
                 const uint32_t st1 = trig ? 1u : (to_scen ? 2u : (to_more ? 3u : ((fail || apply_b) ? 0u : st)));
-                const uint32_t cur1 = trig ? (c0 == 0u ? 1u : 0u)
+                const uint32_t cur1 = trig ? (ctrig == 0u ? 1u : 0u)
                                            : (to_scen ? smin : (to_more ? win : ((adv_c && !end) ? (uint32_t)__ffs(cands) - 1u : cur)));
                 const uint32_t jj1 = (is2 && !s_over) ? jj + 1u : 0u;
                 const uint32_t accn = (trig || to_more) ? 0u : acc1, passn = to_scen ? 0u : pass1;
                 const uint32_t skipn = accept ? (skip ? skip - 1u : 0u) : ((fix && !jump) ? c : skip);
-                const uint32_t prevn = accept ? solb : (fail ? 0u : (apply_b ? 1u : (prev ? 1u : 0u)));
+                const uint32_t prevn = accept ? (acceptB ? (sol2 ? 1u : 0u) : solb) : (fail ? 0u : (apply_b ? 1u : (prev ? 1u : 0u)));
                 S = st1 | (cur1 << S_CUR) | (jj1 << S_JJ) | (accn << S_ACC) | (passn << S_PASS) | (skipn << S_SKIP) | (prevn << S_PREV);
                 // the k-mers: a failed fix copies the trigger base through and keeps it in the k-mer (mod.rs:91-96)
                 const uint64_t kfix = jump ? (((corr << (2u * c)) | (uint64_t)cb) & mask) : corr;
-                kmer = accept ? pk : (fail ? ((corr & ~3ull) | (uint64_t)c0) : (fix ? kfix : kmer));
-                corr = trig ? pk : (to_scen ? ((corr & ~3ull) | (uint64_t)win) : corr);
-                const uint32_t adv = accept ? (first ? 0u : 1u) : (fail ? 1u : (fix ? used + (jump ? c : 0u) : 0u));
+                kmer = accept ? (acceptB ? pk2 : pk) : (fail ? ((corr & ~3ull) | (uint64_t)c0) : (fix ? kfix : kmer));
+                corr = trigA ? pk : (trigB ? pk2 : (to_scen ? ((corr & ~3ull) | (uint64_t)win) : corr));
+                const uint32_t adv = accept ? (first ? 0u : (acceptB ? 2u : 1u)) : (fail ? 1u : (fix ? used + (jump ? c : 0u) : 0u));
                 ev |= (trig ? 2u : 0u) | (fix ? 4u : 0u);
                 if (apply_b) { // mod.rs:75-89: one base out, `used` bases of the read consumed -- the lane's only output
                     if (room) {
@@ -582,7 +618,7 @@ __global__ __launch_bounds__(256, BRX_LANE_WAVES) void lane_kernel(LaneArgs a)
             }
         }
         // every lane back together: count the round's events
-        n_probes += (uint32_t)__builtin_popcountll(__ballot(ev & 1u));
+        n_probes += (uint32_t)__builtin_popcountll(__ballot(ev & 1u)) + (uint32_t)__builtin_popcountll(__ballot(ev & 16u));
         n_trig += (uint32_t)__builtin_popcountll(__ballot(ev & 2u));
         n_fix += (uint32_t)__builtin_popcountll(__ballot(ev & 4u));
         n_miss += (uint32_t)__builtin_popcountll(__ballot(ev & 8u));

@@ -93,6 +93,9 @@ __device__ __forceinline__ uint32_t pack4(uint32_t w)
     return (x | (x >> 12)) & 0xffu;
 }
 
+#ifndef BRX_L1_UNROLL
+#define BRX_L1_UNROLL 4
+#endif
 #ifndef BRX_XCD_ITEMS
 #define BRX_XCD_ITEMS 1
 #endif
@@ -194,8 +197,12 @@ struct L1Args {
     uint64_t out_cap;        // entries of keys_out (checked under BRX_DEBUG_BOUNDS)
 };
 
+// sh_r0[0] = the first read that starts after the tile's first position, upper_bound(offsets, g0): searched for when
+// `search` (17 dependent loads by one thread for 100 000 reads -- about 10 us with everybody else waiting, most of a
+// tile's time when every tile did it), otherwise carried over from the tile before, which counts in sh_r0[1] the reads
+// that start at or before ITS last position while it marks its boundaries: blocks take their tiles in rising order.
 __device__ __forceinline__ void l1_prepare(const L1Args &a, uint32_t item, uint32_t *pk, uint32_t *bnd, uint32_t *sh_r0,
-                                           uint32_t &n_here)
+                                           uint32_t &n_here, bool search)
 {
     const uint64_t off0 = a.offsets[0];
     const uint64_t g0 = (uint64_t)item * L1_TILE;
@@ -206,7 +213,141 @@ __device__ __forceinline__ void l1_prepare(const L1Args &a, uint32_t item, uint3
     for (uint32_t w = threadIdx.x; w < BND_WORDS; w += 256)
         bnd[w] = 0;
     if (threadIdx.x == 0) {
-        // first read that starts after g0: upper_bound(offsets, g0)
+        if (search) {
+            uint32_t lo = 0, hi = a.n_reads + 1;
+            while (lo < hi) {
+                const uint32_t mid = lo + (hi - lo) / 2;
+                if (a.offsets[mid] - off0 <= g0)
+                    lo = mid + 1;
+                else
+                    hi = mid;
+            }
+            sh_r0[0] = lo;
+        } else {
+            sh_r0[0] += sh_r0[1];
+        }
+        sh_r0[1] = 0;
+    }
+    __syncthreads();
+    const uint64_t lim = g0 + n_here + (uint64_t)a.k; // boundaries at window-local positions <= n_here + k - 1 matter
+    uint32_t before_next = 0;
+    for (uint32_t r = sh_r0[0] + threadIdx.x; r <= a.n_reads; r += 256) {
+        const uint64_t o = a.offsets[r] - off0; // offsets[n_reads] - off0 == total: the batch end is a boundary too
+        if (o >= lim)
+            break;
+        const uint32_t p = (uint32_t)(o - g0);
+        atomicOr(&bnd[p >> 5], 1u << (p & 31u));
+        before_next += o <= g0 + L1_TILE ? 1u : 0u;
+    }
+    if (before_next)
+        atomicAdd(&sh_r0[1], before_next);
+    __syncthreads();
+}
+
+// a block's tiles: a contiguous range, taken in rising order
+__device__ __forceinline__ void l1_range(uint32_t n_items, uint32_t &lo, uint32_t &hi)
+{
+    lo = (uint32_t)(((uint64_t)blockIdx.x * n_items) / gridDim.x);
+    hi = (uint32_t)(((uint64_t)(blockIdx.x + 1) * n_items) / gridDim.x);
+}
+
+// The same preparation, one tile ahead.  A tile's global loads -- its bases, the first read offsets behind its start, its
+// row of counts -- are three round trips to memory with everybody waiting (the second depends on sh_r0), and a block has
+// only its own four waves to hide them behind: measured, most of a tile's 13 us.  l1_fetch() issues them for the NEXT
+// tile into registers as soon as sh_r0 of the current one is known; l1_consume() is l1_prepare() fed from them.
+struct L1Next {
+    uint4 q0, q1;  // 16 bases at window word t, and at word 256 + t (the k + 32 bases behind the tile)
+    uint64_t off;  // offsets[r_first + t] - offsets[0]
+    uint32_t m[(1u << MAX_DIGIT_BITS) / 256u]; // matrix[item][t + 256 q] (scatter only)
+};
+
+__device__ __forceinline__ uint32_t l1_window_words(const L1Args &a, uint32_t item, uint32_t &n_here)
+{
+    const uint64_t left = a.total - (uint64_t)item * L1_TILE;
+    n_here = (uint32_t)(left < L1_TILE ? left : L1_TILE);
+    return (n_here + (uint32_t)a.k + 32u + 15u) / 16u; // (+ slack for the 3-word extract)
+}
+
+template <bool ROW>
+__device__ __forceinline__ void l1_fetch(const L1Args &a, uint32_t item, uint32_t r_first, L1Next &nx)
+{
+    const uint64_t off0 = a.offsets[0];
+    const uint8_t *bases = a.bases + off0;
+    const uint64_t g0 = (uint64_t)item * L1_TILE;
+    uint32_t n_here;
+    const uint32_t nwords = l1_window_words(a, item, n_here);
+    const uint64_t p0 = g0 + 16ull * threadIdx.x, p1 = p0 + 16ull * 256ull;
+    nx.q0 = make_uint4(0, 0, 0, 0);
+    nx.q1 = make_uint4(0, 0, 0, 0);
+    if (threadIdx.x < nwords && p0 + 16 <= a.total)
+        __builtin_memcpy(&nx.q0, bases + p0, 16); // one (possibly unaligned) global_load_dwordx4
+    if (256u + threadIdx.x < nwords && p1 + 16 <= a.total)
+        __builtin_memcpy(&nx.q1, bases + p1, 16);
+    const uint32_t r = r_first + threadIdx.x;
+    nx.off = a.offsets[r <= a.n_reads ? r : a.n_reads] - off0;
+    if (ROW) {
+        const uint32_t B = 1u << a.bits;
+#pragma unroll
+        for (uint32_t q = 0; q < (1u << MAX_DIGIT_BITS) / 256u; q++) {
+            const uint32_t b = threadIdx.x + 256u * q;
+            nx.m[q] = b < B ? a.matrix[(uint64_t)item * B + b] : 0u;
+        }
+    }
+}
+
+__device__ __forceinline__ uint32_t l1_pack16(const L1Args &a, const uint4 &q, uint64_t p)
+{
+    uint32_t v[4] = {q.x, q.y, q.z, q.w};
+    if (p + 16 > a.total) { // the batch ends inside these 16 bases (its last tile only): byte by byte, beyond the end reads as A
+        const uint8_t *bases = a.bases + a.offsets[0];
+        v[0] = v[1] = v[2] = v[3] = 0;
+        for (uint32_t j = 0; j < 16; j++)
+            if (p + j < a.total)
+                v[j >> 2] |= (uint32_t)bases[p + j] << (8u * (j & 3u));
+    }
+    return (pack4(v[0]) << 24) | (pack4(v[1]) << 16) | (pack4(v[2]) << 8) | pack4(v[3]);
+}
+
+// nx = l1_fetch(item, sh_r0[0] + sh_r0[1] of the tile before); `first`: sh_r0[0] was searched for, sh_r0[1] == 0
+__device__ __forceinline__ void l1_consume(const L1Args &a, uint32_t item, const L1Next &nx, uint32_t *pk, uint32_t *bnd, uint32_t *sh_r0,
+                                           uint32_t &n_here, bool first)
+{
+    const uint64_t off0 = a.offsets[0];
+    const uint64_t g0 = (uint64_t)item * L1_TILE;
+    const uint32_t nwords = l1_window_words(a, item, n_here);
+    if (threadIdx.x < nwords)
+        pk[threadIdx.x] = l1_pack16(a, nx.q0, g0 + 16ull * threadIdx.x);
+    if (256u + threadIdx.x < nwords)
+        pk[256u + threadIdx.x] = l1_pack16(a, nx.q1, g0 + 16ull * (256u + threadIdx.x));
+    for (uint32_t w = threadIdx.x; w < BND_WORDS; w += 256)
+        bnd[w] = 0;
+    if (threadIdx.x == 0 && !first) {
+        sh_r0[0] += sh_r0[1];
+        sh_r0[1] = 0;
+    }
+    __syncthreads();
+    const uint64_t lim = g0 + n_here + (uint64_t)a.k; // boundaries at window-local positions <= n_here + k - 1 matter
+    uint32_t before_next = 0;
+    uint64_t o = nx.off;
+    for (uint32_t r = sh_r0[0] + threadIdx.x; r <= a.n_reads; r += 256) {
+        if (o >= lim)
+            break;
+        const uint32_t p = (uint32_t)(o - g0);
+        atomicOr(&bnd[p >> 5], 1u << (p & 31u));
+        before_next += o <= g0 + L1_TILE ? 1u : 0u;
+        if (r + 256u <= a.n_reads)
+            o = a.offsets[r + 256u] - off0;
+    }
+    if (before_next)
+        atomicAdd(&sh_r0[1], before_next);
+    __syncthreads();
+}
+
+// upper_bound(offsets, first position of tile `item`) into sh_r0[0], 0 into sh_r0[1]; ends with a barrier
+__device__ __forceinline__ void l1_search(const L1Args &a, uint32_t item, uint32_t *sh_r0)
+{
+    if (threadIdx.x == 0) {
+        const uint64_t off0 = a.offsets[0], g0 = (uint64_t)item * L1_TILE;
         uint32_t lo = 0, hi = a.n_reads + 1;
         while (lo < hi) {
             const uint32_t mid = lo + (hi - lo) / 2;
@@ -215,16 +356,8 @@ __device__ __forceinline__ void l1_prepare(const L1Args &a, uint32_t item, uint3
             else
                 hi = mid;
         }
-        *sh_r0 = lo;
-    }
-    __syncthreads();
-    const uint64_t lim = g0 + n_here + (uint64_t)a.k; // boundaries at window-local positions <= n_here + k - 1 matter
-    for (uint32_t r = *sh_r0 + threadIdx.x; r <= a.n_reads; r += 256) {
-        const uint64_t o = a.offsets[r] - off0; // offsets[n_reads] - off0 == total: the batch end is a boundary too
-        if (o >= lim)
-            break;
-        const uint32_t p = (uint32_t)(o - g0);
-        atomicOr(&bnd[p >> 5], 1u << (p & 31u));
+        sh_r0[0] = lo;
+        sh_r0[1] = 0;
     }
     __syncthreads();
 }
@@ -244,7 +377,7 @@ __device__ __forceinline__ bool l1_valid(const uint32_t *bnd, uint32_t p, int k)
 // cutting every k-mer out of pk[] (three LDS reads, a funnel shift, a 64-bit bit reversal) and testing the boundary
 // bitmap with two more LDS reads per position.  Both level-1 kernels are bound by the instructions they issue.
 static_assert(L1_TILE == 256u * 16u, "l1_for_each_hash: 16 positions per thread");
-template <typename F>
+template <int UNROLL = 4, typename F>
 __device__ __forceinline__ void l1_for_each_hash(const uint32_t *__restrict__ pk, const uint32_t *__restrict__ bnd, uint32_t n_here,
                                                  int k, F &&f)
 {
@@ -265,7 +398,7 @@ __device__ __forceinline__ void l1_for_each_hash(const uint32_t *__restrict__ pk
     const uint64_t vmask = k > 1 ? (1ull << (k - 1)) - 1ull : 0ull;
     const uint32_t left = n_here - p0 < 16u ? n_here - p0 : 16u;
     const int top = 2 * k - 2;
-#pragma unroll 4
+#pragma unroll UNROLL
     for (uint32_t j = 0; j < left; j++) {
         if ((vb & vmask) == 0ull)
             f(((popc64(fwd) & 1) ? rc : fwd) >> 1);
@@ -282,15 +415,23 @@ __global__ __launch_bounds__(256) void l1_hist_kernel(L1Args a)
     extern __shared__ uint32_t lds[]; // hist[B]
     __shared__ uint32_t pk[PACK_WORDS];
     __shared__ uint32_t bnd[BND_WORDS];
-    __shared__ uint32_t sh_r0;
+    __shared__ uint32_t sh_r0[2];
     const uint32_t B = 1u << a.bits;
     const int shift = a.nbits - a.bits;
-    const ItemRange ir = xcd_items(a.n_items);
-    for (uint32_t item = (uint32_t)ir.first; item < (uint32_t)ir.end; item += (uint32_t)ir.step) {
+    uint32_t lo, hi;
+    l1_range(a.n_items, lo, hi);
+    if (lo >= hi)
+        return;
+    l1_search(a, lo, sh_r0);
+    L1Next nx;
+    l1_fetch<false>(a, lo, sh_r0[0], nx);
+    for (uint32_t item = lo; item < hi; item++) {
         for (uint32_t b = threadIdx.x; b < B; b += 256)
             lds[b] = 0;
         uint32_t n_here;
-        l1_prepare(a, item, pk, bnd, &sh_r0, n_here);
+        l1_consume(a, item, nx, pk, bnd, sh_r0, n_here, item == lo);
+        if (item + 1 < hi)
+            l1_fetch<false>(a, item + 1, sh_r0[0] + sh_r0[1], nx);
         l1_for_each_hash(pk, bnd, n_here, a.k, [&](uint64_t h) { atomicAdd(&lds[(uint32_t)(h >> shift)], 1u); });
         __syncthreads();
         for (uint32_t b = threadIdx.x; b < B; b += 256)
@@ -407,11 +548,13 @@ __global__ __launch_bounds__(256) void flat_insert_kernel(L1Args a, uint32_t *__
 {
     __shared__ uint32_t pk[PACK_WORDS];
     __shared__ uint32_t bnd[BND_WORDS];
-    __shared__ uint32_t sh_r0;
+    __shared__ uint32_t sh_r0[2];
     uint32_t added = 0;
-    for (uint32_t item = blockIdx.x; item < a.n_items; item += gridDim.x) {
+    uint32_t lo, hi;
+    l1_range(a.n_items, lo, hi);
+    for (uint32_t item = lo; item < hi; item++) {
         uint32_t n_here;
-        l1_prepare(a, item, pk, bnd, &sh_r0, n_here);
+        l1_prepare(a, item, pk, bnd, sh_r0, n_here, item == lo);
         for (uint32_t p = threadIdx.x; p < n_here; p += 256)
             if (l1_valid(bnd, p, a.k)) {
                 const uint64_t kmer = kmer_at(pk, p, a.k);
@@ -465,49 +608,127 @@ __device__ __forceinline__ void block_scan_bins(uint32_t B, const uint32_t *cntv
     }
 }
 
-__global__ __launch_bounds__(256) void l1_scatter_kernel(L1Args a)
+// Level-1 write-out in whole 32-byte sectors.  A tile leaves T / B = 8 keys per digit on average: written where they
+// belong, that is a 32-byte run at a 4-byte-aligned place, 1.87 sectors touched per run (WRITE_SIZE counted exactly that,
+// profiles/r2j_*), every one of them a partial write.  But the runs of one digit from CONSECUTIVE tiles lie end to end
+// (pos[t + 1][d] = pos[t][d] + count[t][d]), so a block that takes a contiguous range of tiles can hold back the keys
+// behind each digit's last sector boundary (a carry of < 8 keys per digit, in LDS) and write them with the next tile's:
+// only the two ends of a block's range are partial.  The first sector of a range starts with the `ph` places that belong
+// to the range before (phantoms: kept as holes in the carry, never stored).
+constexpr uint32_t L1_SECTOR = 8;                              // keys per 32-byte sector
+constexpr uint32_t L1_OWN = ((1u << MAX_DIGIT_BITS) + 255u) / 256u; // digits per lane: t, t + 256
+
+__global__ __launch_bounds__(256, 5) void l1_scatter_kernel(L1Args a)
 {
-    // LDS: stage_key[T] (u32) | stage_dig[T] (u16) | gbase[B] (u64) | cnt[B] | lofs[B] | lcur[B]
+    // LDS: stage_key[T] | gsm[B] (u64: sector index | keys carried << 32 | phantoms << 36) | cnt[B] | lofs[B] | lcur[B]
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     __shared__ uint32_t pk[PACK_WORDS];
     __shared__ uint32_t bnd[BND_WORDS];
-    __shared__ uint32_t sh_r0;
+    __shared__ uint32_t sh_r0[2];
     __shared__ uint32_t sh_wsum[4];
     const uint32_t T = L1_TILE;
     const uint32_t B = 1u << a.bits;
     uint32_t *stage_key = (uint32_t *)lds_raw;
-    uint16_t *stage_dig = (uint16_t *)(lds_raw + (size_t)T * 4);
-    unsigned long long *gbase = (unsigned long long *)(lds_raw + (size_t)T * 6);
-    uint32_t *cntv = (uint32_t *)(lds_raw + (size_t)T * 6 + (size_t)B * 8);
+    unsigned long long *gsm = (unsigned long long *)(stage_key + T);
+    uint32_t *cntv = (uint32_t *)(gsm + B);
     uint32_t *lofs = cntv + B;
     uint32_t *lcur = lofs + B;
     const int shift = a.nbits - a.bits;
     const uint64_t child_mask = (1ull << shift) - 1ull;
-    const ItemRange ir = xcd_items(a.n_items);
-    for (uint32_t item = (uint32_t)ir.first; item < (uint32_t)ir.end; item += (uint32_t)ir.step) {
-        for (uint32_t b = threadIdx.x; b < B; b += 256) {
-            cntv[b] = a.matrix[(uint64_t)item * B + b]; // the histogram pass already counted this tile
-            gbase[b] = a.pos[(uint64_t)item * B + b];
-        }
+    uint32_t lo, hi;
+    l1_range(a.n_items, lo, hi);
+    if (lo >= hi)
+        return;
+    for (uint32_t b = threadIdx.x; b < B; b += 256) {
+        const unsigned long long p0 = a.pos[(uint64_t)lo * B + b];
+        const unsigned long long ph = p0 & (L1_SECTOR - 1);
+        gsm[b] = (p0 / L1_SECTOR) | (ph << 32) | (ph << 36);
+    }
+    uint32_t creg[L1_OWN][L1_SECTOR]; // the carries of this lane's digits
+#pragma unroll
+    for (uint32_t q = 0; q < L1_OWN; q++)
+#pragma unroll
+        for (uint32_t jj = 0; jj < L1_SECTOR; jj++)
+            creg[q][jj] = 0;
+    l1_search(a, lo, sh_r0);
+    L1Next nx;
+    l1_fetch<true>(a, lo, sh_r0[0], nx);
+    for (uint32_t item = lo; item < hi; item++) {
+#pragma unroll
+        for (uint32_t q = 0; q < L1_OWN; q++)
+            if (threadIdx.x + 256u * q < B)
+                cntv[threadIdx.x + 256u * q] = nx.m[q]; // the histogram pass already counted this tile
         uint32_t n_here;
-        l1_prepare(a, item, pk, bnd, &sh_r0, n_here);
+        l1_consume(a, item, nx, pk, bnd, sh_r0, n_here, item == lo);
+        if (item + 1 < hi)
+            l1_fetch<true>(a, item + 1, sh_r0[0] + sh_r0[1], nx);
         block_scan_bins(B, cntv, lofs, lcur, sh_wsum);
         __syncthreads();
-        l1_for_each_hash(pk, bnd, n_here, a.k, [&](uint64_t h) {
+        l1_for_each_hash<BRX_L1_UNROLL>(pk, bnd, n_here, a.k, [&](uint64_t h) {
             const uint32_t d = (uint32_t)(h >> shift);
             const uint32_t slot = atomicAdd(&lcur[d], 1u);
             stage_key[slot] = (uint32_t)(h & child_mask);
-            stage_dig[slot] = (uint16_t)d;
         });
         __syncthreads();
-        const uint32_t n_tile = lofs[B - 1] + cntv[B - 1];
-        for (uint32_t idx = threadIdx.x; idx < n_tile; idx += 256) {
-            const uint32_t d = stage_dig[idx];
-            const uint64_t at = gbase[d] + (idx - lofs[d]);
-            if (store_ok(at, a.out_cap))
-                a.keys_out[at] = stage_key[idx];
+        // one digit per lane: carry + the tile's keys leave as whole sectors (two 16-byte stores), the rest is the new carry
+#pragma unroll
+        for (uint32_t q = 0; q < L1_OWN; q++) {
+            const uint32_t d = threadIdx.x + 256u * q;
+            if (d < B) {
+                const unsigned long long m = gsm[d];
+                const uint32_t n = cntv[d], base = lofs[d];
+                const uint32_t gsx = (uint32_t)m, cc = (uint32_t)(m >> 32) & 15u, ph = (uint32_t)(m >> 36) & 15u;
+                const uint32_t tot = cc + n, full = tot / L1_SECTOR, r = tot % L1_SECTOR;
+                const uint32_t src = base - cc; // element e >= cc of the run is stage_key[src + e]
+                uint32_t *out = a.keys_out + (unsigned long long)gsx * L1_SECTOR;
+                for (uint32_t sct = 0; sct < full; sct++) {
+                    uint32_t v[L1_SECTOR];
+#pragma unroll
+                    for (uint32_t jj = 0; jj < L1_SECTOR; jj++) {
+                        const uint32_t e = L1_SECTOR * sct + jj;
+                        v[jj] = e < cc ? creg[q][jj] : stage_key[src + e];
+                    }
+                    if (store_ok((unsigned long long)(gsx + sct) * L1_SECTOR + 7u, a.out_cap)) {
+                        if (sct == 0 && ph) { // the first sector of the range: its first places are the range before's
+#pragma unroll
+                            for (uint32_t jj = 0; jj < L1_SECTOR; jj++)
+                                if (jj >= ph)
+                                    out[jj] = v[jj];
+                        } else {
+                            uint4 *o4 = reinterpret_cast<uint4 *>(out + L1_SECTOR * sct);
+                            o4[0] = make_uint4(v[0], v[1], v[2], v[3]);
+                            o4[1] = make_uint4(v[4], v[5], v[6], v[7]);
+                        }
+                    }
+                }
+                if (full) {
+#pragma unroll
+                    for (uint32_t jj = 0; jj < L1_SECTOR; jj++)
+                        creg[q][jj] = jj < r ? stage_key[src + L1_SECTOR * full + jj] : 0u;
+                    gsm[d] = (unsigned long long)(gsx + full) | ((unsigned long long)r << 32);
+                } else {
+#pragma unroll
+                    for (uint32_t jj = 0; jj < L1_SECTOR; jj++)
+                        creg[q][jj] = jj < cc ? creg[q][jj] : (jj < r ? stage_key[src + jj] : 0u);
+                    gsm[d] = (unsigned long long)gsx | ((unsigned long long)r << 32) | ((unsigned long long)ph << 36);
+                }
+            }
         }
         __syncthreads();
+    }
+    // the end of the range: what is still held back
+#pragma unroll
+    for (uint32_t q = 0; q < L1_OWN; q++) {
+        const uint32_t d = threadIdx.x + 256u * q;
+        if (d < B) {
+            const unsigned long long m = gsm[d];
+            const uint32_t cc = (uint32_t)(m >> 32) & 15u, ph = (uint32_t)(m >> 36) & 15u;
+            const unsigned long long g = (unsigned long long)(uint32_t)m * L1_SECTOR;
+#pragma unroll
+            for (uint32_t jj = 0; jj < L1_SECTOR; jj++)
+                if (jj >= ph && jj < cc && store_ok(g + jj, a.out_cap))
+                    a.keys_out[g + jj] = creg[q][jj];
+        }
     }
 }
 
@@ -1488,6 +1709,12 @@ static size_t scatter_lds_bytes(uint32_t tile, int bits)
     return (size_t)tile * 6 + B * 8 + B * 12 + 64;
 }
 
+static size_t l1_scatter_lds_bytes(int bits)
+{
+    const size_t B = (size_t)1 << bits;
+    return (size_t)L1_TILE * 4 + B * 8 + B * 12 + 64; // keys, sector index + carry state, three counters
+}
+
 int part_add_batch(brx_counter *c, const uint8_t *d_bases, const uint64_t *d_offsets, uint32_t n_reads,
                    uint64_t total_bases, hipStream_t s)
 {
@@ -1532,7 +1759,12 @@ int part_add_batch(brx_counter *c, const uint8_t *d_bases, const uint64_t *d_off
     a.pos = st->d_pos;
     a.keys_out = b.d_keys;
     a.out_cap = b.cap;
-    const int grid = n_items < 2048u ? (int)n_items : 2048;
+    // both level-1 kernels give a block a contiguous range of tiles (BRX_L1_GRID: tests shrink the grid so that small
+    // inputs give every block several tiles)
+    const char *genv = getenv("BRX_L1_GRID");
+    const long gev = genv ? atol(genv) : 0;
+    const uint32_t hist_blocks = gev > 0 ? (uint32_t)gev : 2048u, scatter_blocks = gev > 0 ? (uint32_t)gev : 2560u;
+    const int grid = (int)(n_items < hist_blocks ? n_items : hist_blocks);
     {
         KernelTimer t("part_l1_hist", s);
         l1_hist_kernel<<<grid, 256, (size_t)B * 4, s>>>(a);
@@ -1556,10 +1788,13 @@ int part_add_batch(brx_counter *c, const uint8_t *d_bases, const uint64_t *d_off
     }
     {
         KernelTimer t("part_l1_scatter", s);
-        const size_t lds1 = scatter_lds_bytes(L1_TILE, a.bits);
+        const size_t lds1 = l1_scatter_lds_bytes(a.bits);
         if (lds1 > 64 * 1024)
             BRX_HIP(hipFuncSetAttribute((const void *)l1_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
-        l1_scatter_kernel<<<grid, 256, lds1, s>>>(a);
+        // contiguous tile ranges, one per block (the kernel's carries): twice the blocks the chip holds at once
+        // (5 per CU at 27 KB of LDS): the ranges stay long (~100 tiles at 1 Gbp) and the last round of blocks short
+        const uint32_t sgrid = n_items < scatter_blocks ? n_items : scatter_blocks;
+        l1_scatter_kernel<<<sgrid, 256, lds1, s>>>(a);
     }
     trace_stage(s, "partition level 1: scatter");
     BRX_HIP(hipGetLastError());

@@ -149,6 +149,43 @@ def test_partitioned_huge_bucket():
         assert gs.to_solid_bytes() == ref.to_bytes()
 
 
+@pytest.mark.parametrize("blocks", ["1", "3", "7"])
+@pytest.mark.parametrize("k", [13, 15, 19])
+def test_partitioned_level1_tile_ranges(raw_reads, monkeypatch, k, blocks):
+    """Level 1 of the partitioned build gives every block a contiguous range of 4096-position tiles and carries state from
+    tile to tile (the read index, the keys behind each digit's last 32-byte sector).  Small inputs are one tile per block:
+    BRX_L1_GRID shrinks the grid so that ranges of many tiles, their first-sector phantoms and their final flush are run
+    against the oracle -- with short reads (many boundaries per tile), empty reads, and low-complexity reads that put
+    whole tiles into one digit.  k = 19: against the sparse oracle (the dense one would need 128 GiB of counters)."""
+    monkeypatch.setenv("BRX_L1_GRID", blocks)
+    rng = np.random.default_rng(100 + k)
+    short = [bytes(rng.choice(list(b"ACGT"), size=int(n)).astype(np.uint8)) for n in rng.integers(0, 60, size=600)]
+    reads = raw_reads[:30] + [b"A" * 9000, b"", b"ACACACACAC" * 700, b"T" * 5000] + short + raw_reads[30:45] + [b"G" * 4100]
+    assert sum(len(r) for r in reads) > 20 * 4096
+    for a in (0, 2):
+        gs = br_amd.Pcon.from_count(reads, k, a, strategy=_lib.COUNT_SORTED)
+        if k <= 15:
+            ref = O.Solid.from_count(k, O.count_reads(k, reads), a)
+            assert gs.to_solid_bytes() == ref.to_bytes()
+        else:
+            ref = O.Solid.sparse_from_count(k, reads, a)
+            assert gs.popcount() == ref.popcount() > 1000
+            kmers = _kmers_of(reads[:40:3], k)
+            got = gs.get_many(kmers)
+            assert np.array_equal(got, np.array([ref.get(int(x)) for x in kmers]))
+            assert got.any() and (a == 0 or not got.all())
+
+
+def _kmers_of(reads, k):
+    out = []
+    for r in reads:
+        for i in range(0, len(r) - k + 1, 5):
+            w = r[i:i + k]
+            if set(w) <= set(b"ACGT"):
+                out.append(O.seq2bit(w))
+    return np.array(out, dtype=np.uint64)
+
+
 def test_presence_build_vs_oracle(raw_reads):
     k = 13
     reads = raw_reads[:25]
