@@ -359,7 +359,8 @@ def main():
                        "correct_only_gbases_per_s": round(total * args.steps / (phase_ms["correct"] * 1e-3) / 1e9, 3)
                        if phase_ms["correct"] > 0 else None,
                        "build_only_gbases_per_s": round(total * args.steps / (phase_ms["build"] * 1e-3) / 1e9, 3)
-                       if phase_ms["build"] > 0 else None},
+                       if phase_ms["build"] > 0 else None,
+                       **build_roofline(prof, total, args.steps, phase_ms["build"])},
             "kernels": {n: {"avg_ms": round(v["total_ms"] / max(v["launches"], 1), 4), "launches": v["launches"]}
                         for n, v in prof.items() if v["launches"]},
             "correct_stats": {**{k_: int(v) for k_, v in stats.items()}, "out_bases": int(out_total),
@@ -469,6 +470,23 @@ def cpu_baseline(args, cfg, gs, k, n_reads):
     except MemoryError:
         res["set_build"] = {"value": None, "sample": "host table of k=%d did not fit" % kb}
     return res
+
+
+def build_roofline(prof, total, steps, build_ms):
+    """The set build against the bytes its own passes must move: the partitioned build reads the
+    bases twice at level 1 (histogram, scatter: 1 B each) and writes a 4-byte key per k-mer, reads the keys twice and
+    writes them once at every further level (12 B), and reads them once more in the final count (4 B); the index
+    build and the threshold output are a few bytes per SOLID k-mer, not per base, and are left out.  SURVEY 8(d)'s
+    figure for the set build -- 129 B per base, one 64-byte counter line read and written back per k-mer -- is the
+    dense-counter algorithm's; it is quoted beside it."""
+    levels = sum(1 for n_ in prof if n_.startswith("part_l") and n_.endswith("_scatter") and prof[n_]["launches"])
+    if not levels or build_ms <= 0:
+        return {}
+    per_base = 2 + 4 + 12 * (levels - 1) + 4
+    rate = per_base * total * steps / (build_ms * 1e-3) / 1e9
+    return {"build_bytes_per_base": per_base, "build_levels": levels, "build_gbs": round(rate, 1),
+            "build_frac": round(rate / HBM_PEAK_GBS, 4),
+            "build_frac_survey_model": round(129 * total * steps / (build_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
 
 
 def host_8192(args, d_bases, d_off, n_reads, gs):
