@@ -75,7 +75,9 @@ while time.time() < t_end:
            "BRX_HASH_FINAL": str(rng.choice(["", "", "0"])),
            # One's forward pass cut into units (brx_onelane.hip): off, tiny chunks, sync runs from sloppy to strict
            "BRX_LANE": str(rng.choice(["", "", "", "0"])), "BRX_LANE_CHUNK": str(rng.choice(["", "64", "100", "333"])),
-           "BRX_LANE_SYNC": str(rng.choice(["", "1", "2", "8"])), "BRX_LANE_WALK": str(rng.choice(["", "", "", "0"]))}
+           "BRX_LANE_SYNC": str(rng.choice(["", "1", "2", "8"])), "BRX_LANE_WALK": str(rng.choice(["", "", "", "0"])),
+           # level 1 of the partitioned build: blocks that take many tiles each even on small inputs
+           "BRX_L1_GRID": str(rng.choice(["", "", "1", "5"]))}
     for key, v in env.items():
         if v == "":
             os.environ.pop(key, None)
