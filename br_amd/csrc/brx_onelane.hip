@@ -1780,6 +1780,7 @@ int lane_pass(brx_chain *ch, const PassParams &p, const LanePassInfo &info, hipS
     const uint64_t p_bound = (info.in_total_bound >> 4) + 5ull * p.n_reads + 16ull;                        // dwords
     const uint64_t e_bound = (info.in_total_bound >> 2) + 16ull * (units_bound + 2ull * p.n_reads) + 64ull; // entries
     if (w->reads_cap < p.n_reads) {
+        w->reads_cap = 0; // (a growth that fails half-way leaves freed pointers: nothing here may be trusted then)
         const uint64_t cap = (uint64_t)p.n_reads + p.n_reads / 8 + 64;
         BRX_TRY(grow_dev((void **)&w->nu, cap * 4));
         BRX_TRY(grow_dev((void **)&w->fail_list, cap * 4));
@@ -1787,6 +1788,7 @@ int lane_pass(brx_chain *ch, const PassParams &p, const LanePassInfo &info, hipS
         w->reads_cap = cap;
     }
     if (w->units_cap < units_bound) {
+        w->units_cap = 0; // (a growth that fails half-way leaves freed pointers: nothing here may be trusted then)
         const uint64_t cap = units_bound + units_bound / 8 + 64;
         BRX_TRY(grow_dev((void **)&w->u_read, cap * 4));
         BRX_TRY(grow_dev((void **)&w->u_q, cap * 4));
@@ -1797,17 +1799,20 @@ int lane_pass(brx_chain *ch, const PassParams &p, const LanePassInfo &info, hipS
         w->units_cap = cap;
     }
     if (w->p_cap < p_bound) {
+        w->p_cap = 0; // (a growth that fails half-way leaves freed pointers: nothing here may be trusted then)
         const uint64_t cap = p_bound + p_bound / 16;
         BRX_TRY(grow_dev((void **)&w->P, cap * 4));
         w->p_cap = cap;
     }
     if (w->e_cap < e_bound) {
+        w->e_cap = 0; // (a growth that fails half-way leaves freed pointers: nothing here may be trusted then)
         const uint64_t cap = e_bound + e_bound / 16;
         for (int d = 0; d < MAX_DEPTH; d++)
             BRX_TRY(grow_dev((void **)&w->E[d], cap * 4));
         w->e_cap = cap;
     }
     if (walk && w->bw_cap < e_bound) {
+        w->bw_cap = 0;
         const uint64_t cap = e_bound + e_bound / 16;
         for (int d = 0; d < MAX_DEPTH; d++)
             BRX_TRY(grow_dev((void **)&w->BW[d], cap * 4));
