@@ -296,7 +296,7 @@ def main():
     # A forward pass in lane form is several launches (unit tables + packed copy, sync points, the automaton, the replay
     # of its fixes, the few reads handed back; the successor table of a set for the walking methods): their time belongs
     # to the pass, so the launch average below is (everything the passes cost) / (passes)
-    LANE_AUX = ("lane_units", "lane_sync", "lane_apply", "lane_redo", "succ_build")
+    LANE_AUX = ("lane_units", "lane_mask", "lane_sync", "lane_apply", "lane_redo", "succ_build")
     aux_ms = sum(prof[n_]["total_ms"] for n_ in LANE_AUX if n_ in prof)
     if dominant:
         pass_ms = prof[dominant]["total_ms"] + (aux_ms if dominant.startswith("correct_pass") else 0.0)

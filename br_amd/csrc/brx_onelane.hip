@@ -54,7 +54,7 @@ constexpr uint32_t C_FAIL = 0xfffffff1u;   // res[6]: three misses in a row, or 
 constexpr uint32_t C_VOID = 0xfffffff2u;   // res[6]: nothing produced
 constexpr int MAX_DEPTH = 3;               // edit lists: own stretch + two stretches scanned after a miss
 constexpr uint32_t MAX_LANE_READ = 1u << 28; // positions are kept in 28 bits of an edit
-constexpr uint32_t AP_EDITS = 1024; // fixes replayed per batch
+constexpr uint32_t AP_EDITS = 512;  // fixes replayed per batch
 constexpr uint32_t AP_PIECES = 256; // pieces (unit, depth) gathered per batch
 constexpr uint32_t APW_EDITS = 512; // ... by the walking correctors' replay kernel
 constexpr uint32_t AP_VERIFY = 1024; // longest fixed-length walk whose k-mers the replay kernel checks for a repeat
@@ -77,6 +77,7 @@ struct LaneArgs {
     uint32_t *u_res;           // n0 t1 n1 t2 n2 t3 code -                  [8 x units]
     UnitDesc *u_desc;          // what a lane loads to start on a unit      [units]
     uint32_t *P;               // the batch as 2-bit codes, 16 bases per dword, first base in the top bits
+    uint16_t *M;               // beside every dword of P: bit j = the ORIGINAL k-mer that ends at its base j is solid (or null)
     uint32_t *E[MAX_DEPTH];    // edit lists: pos << 4 | consumed << 2 | base
     uint2 *EW[MAX_DEPTH];      // the walking correctors' lists: pos, consumed << 16 | bases written (same memory as E)
     uint32_t *BW[MAX_DEPTH];   // ... and the written bases, 16 per word, a fix starting a word
@@ -184,6 +185,77 @@ __device__ __forceinline__ bool set_get(const PassParams &p, uint64_t km, int k)
     }
 }
 
+// Which ORIGINAL k-mers of the batch are solid, one bit per position (a.M, laid out like P): asked once, in parallel, 64
+// neighbouring positions per wave -- neighbours share their index lines, so this is the cheap way to ask.  The automata
+// then scan stretches the reads' own bases cover (no fix inside the last k - 1 positions) from these bits, many
+// positions per round and without a probe.  A wave per unit, the unit's nominal stretch cut at multiples of 16.
+template <bool IDX>
+__global__ __launch_bounds__(256) void lane_mask_kernel(LaneArgs a)
+{
+    const PassParams &p = a.p;
+    const int lane = threadIdx.x & 63;
+    const int k = p.k;
+    const uint64_t mask = kmask(k);
+    const unsigned long long n_units = p.ctrl[CTL_LANE_UNITS];
+    const unsigned long long wave = (unsigned long long)blockIdx.x * 4ull + (threadIdx.x >> 6);
+    const unsigned long long n_waves = (unsigned long long)gridDim.x * 4ull;
+    uint4 ui_next = wave < n_units ? a.u_in[wave] : make_uint4(0, 0, 0, 0);
+    uint32_t r_next = wave < n_units ? a.u_read[wave] : 0u;
+    for (unsigned long long u = wave; u < n_units; u += n_waves) {
+        const uint4 ui = ui_next;
+        const uint32_t r = r_next;
+        if (u + n_waves < n_units) {
+            ui_next = a.u_in[u + n_waves];
+            r_next = a.u_read[u + n_waves];
+        }
+        const uint32_t j = ui.w, n = ui.z;
+        const uint64_t at = ((uint64_t)ui.y << 32) | ui.x;
+        const bool last = (uint64_t)j + 1ull == a.ubase[r + 1] - a.ubase[r];
+        const uint32_t s = (j * a.C) & ~15u; // (>= 64 for j >= 1: C >= 64)
+        const uint32_t lim = last ? n : ((j + 1u) * a.C) & ~15u;
+        const uint32_t *row = a.P + pack_start(at, r);
+        uint16_t *mrow = a.M + pack_start(at, r);
+        // the 31 bases in front of s: what the first k-mers of the stretch reach back into
+        uint64_t carry = 0;
+        if (s) {
+            const uint32_t b = s - 31u, w = b >> 4, sh = 2u * (b & 15u);
+            const uint64_t hi = ((uint64_t)row[w] << 32) | row[w + 1];
+            const uint64_t lo = row[w + 2];
+            carry = (sh ? ((hi << sh) | (lo >> (32u - sh))) : hi) >> 2;
+        }
+        for (uint32_t e0 = s; e0 < lim; e0 += 64u) {
+            const uint32_t e = e0 + (uint32_t)lane;
+            const uint32_t code = (row[e >> 4] >> (30u - 2u * (e & 15u))) & 3u; // (the padding behind the read packs as A)
+            const uint64_t km = lane_kmer64_dpp(carry, code, lane, mask);
+            bool sol = false;
+            if (e < lim && e + 1u >= (uint32_t)k) {
+                if (IDX) {
+                    uint64_t key;
+                    const uint32_t home = index_locate(p.idx, km, k, key);
+                    // an empty home line answers from its occupancy bit (4 MiB, L2-resident), most k-mers with an error do
+                    if (!p.idx.line_bits || ((p.idx.line_bits[home >> 5] >> (home & 31u)) & 1u)) {
+                        int pr = index_probe_at(p.idx, key, home, 0u);
+                        for (uint32_t hop = 1; pr == 2 && !p.bits; hop++)
+                            pr = index_probe_at(p.idx, key, home, hop);
+                        if (pr == 2) {
+                            const uint64_t h = key - 1ull;
+                            pr = (p.bits[h >> 5] >> (h & 31u)) & 1u;
+                        }
+                        sol = pr == 1;
+                    }
+                } else {
+                    sol = probe(p.bits, km, k);
+                }
+            }
+            const uint64_t ball = __ballot(sol);
+            if ((lane & 15) == 0 && e < lim)
+                mrow[e >> 4] = (uint16_t)(ball >> lane);
+            carry = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(km >> 32), 63) << 32) |
+                    (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)km, 63);
+        }
+    }
+}
+
 // One wave per unit boundary: the first position q > j*C + k behind R solid original k-mers in a row, inside the unit's
 // own nominal stretch; none -> the unit is void.  q is the loop-top position (mod.rs:68), u_qk the k-mer in front of it.
 template <bool IDX>
@@ -239,6 +311,59 @@ __global__ __launch_bounds__(256) void lane_sync_kernel(LaneArgs a)
             a.u_q[u] = q;
             a.u_qk[u] = qk;
         }
+    }
+}
+
+// The same sync points read off the solidity mask (when lane_mask_kernel has run): one THREAD per unit, sixteen
+// positions per step -- a run of R set bits that lies inside the unit's nominal stretch.
+__global__ __launch_bounds__(256) void lane_sync_mask_kernel(LaneArgs a)
+{
+    const PassParams &p = a.p;
+    const uint32_t k = (uint32_t)p.k;
+    const unsigned long long n_units = p.ctrl[CTL_LANE_UNITS];
+    for (unsigned long long u = (unsigned long long)blockIdx.x * 256ull + threadIdx.x; u < n_units; u += (unsigned long long)gridDim.x * 256ull) {
+        const uint4 ui = a.u_in[u];
+        const uint32_t j = ui.w, n = ui.z;
+        if (j == 0) {
+            a.u_q[u] = 0;
+            continue;
+        }
+        const uint32_t r = a.u_read[u];
+        const uint64_t at = ((uint64_t)ui.y << 32) | ui.x;
+        const uint32_t *row = a.P + pack_start(at, r);
+        const uint16_t *mrow = a.M + pack_start(at, r);
+        const uint32_t s = j * a.C;
+        const uint32_t lim = (s + a.C < n) ? s + a.C : n; // k-mers ending at e < lim ...
+        const uint32_t e0 = s + k - 1u;                    // ... and starting at or behind s
+        uint32_t q = U_VOID;
+        uint64_t qk = 0;
+        uint64_t w = 0; // the last 64 answers, the newest sixteen in the top bits
+        for (uint32_t g = e0 >> 4; 16u * g < lim; g++) {
+            uint32_t bits = mrow[g];
+            const uint32_t base = 16u * g;
+            if (base < e0)
+                bits &= 0xffffu << (e0 - base);
+            if (base + 16u > lim)
+                bits &= 0xffffu >> (base + 16u - lim);
+            w = (w >> 16) | ((uint64_t)bits << 48);
+            uint64_t t = w;
+            for (uint32_t rr = 1; rr < a.R; rr++)
+                t &= w << rr;
+            const uint32_t hit = (uint32_t)(t >> 48);
+            if (hit) {
+                const uint32_t el = base + (uint32_t)__builtin_ctz(hit); // the run's last k-mer ends here
+                if (el + 1u < n) {
+                    q = el + 1u;
+                    const uint32_t b = el + 1u - k, wd = b >> 4, sh = 2u * (b & 15u);
+                    const uint64_t hi = ((uint64_t)row[wd] << 32) | row[wd + 1];
+                    const uint64_t lo = row[wd + 2];
+                    qk = (sh ? ((hi << sh) | (lo >> (32u - sh))) : hi) >> (64u - 2u * k);
+                }
+                break;
+            }
+        }
+        a.u_q[u] = q;
+        a.u_qk[u] = qk;
     }
 }
 
@@ -304,10 +429,11 @@ __global__ __launch_bounds__(256) void lane_link_kernel(LaneArgs a)
 //         1 ALTS  probe the trigger k-mer with last base cur   mod.rs:114-128 (the read's own base is known not solid)
 //         2 SCEN  probe corr + seq[off .. off+jj]            exist/mod.rs:33-41  (scenario cur: I / S / D, off = 2 - cur)
 //         3 MORE  probe corr + seq[off .. off+c]             exist/mod.rs:57-66
-enum { S_ST = 0, S_CUR = 2, S_JJ = 4, S_ACC = 8, S_PASS = 12, S_SKIP = 24, S_PREV = 27, S_FIRST = 28, S_SLOW = 29 };
+enum { S_ST = 0, S_CUR = 2, S_JJ = 4, S_ACC = 8, S_PASS = 12, S_DIRTY = 16, S_SKIP = 24, S_PREV = 27, S_FIRST = 28, S_SLOW = 29 };
+constexpr uint32_t MASK_STEP = 16; // positions a clean SCAN round takes at most: what a round's refill puts back into the window
 
-template <bool IDX, int KT>
-__global__ __launch_bounds__(256, BRX_LANE_WAVES) void lane_kernel(LaneArgs a)
+template <bool IDX, int KT, bool MASK>
+__global__ __launch_bounds__(256, MASK ? 6 : BRX_LANE_WAVES) void lane_kernel(LaneArgs a)
 {
     const PassParams &p = a.p;
     const int k = KT ? KT : p.k;
@@ -329,6 +455,11 @@ __global__ __launch_bounds__(256, BRX_LANE_WAVES) void lane_kernel(LaneArgs a)
     // the bases ahead: positions i .. i+wcnt of the read, 2 bits each, position i in the top bits; the next 16 in nextw
     uint64_t wreg = 0;
     uint32_t wcnt = 0, nextw = 0, pidx = 0;
+    // ... and whether the ORIGINAL k-mers that end at them are solid (lane_mask_kernel): bit j of mw for position i + j,
+    // wcnt bits of it, the next 16 in nextm.  A stretch of the scan whose k-mers hold no corrected base (S_DIRTY == 0)
+    // is read off these bits, up to MASK_STEP positions per round, without a probe.
+    constexpr bool use_mask = MASK; // (a variant of its own: the masked form needs 6 registers more than 7 waves leave)
+    uint32_t mw = 0, nextm = 0;
     // the scan (mod.rs:60-67) and the trigger in progress
     uint64_t kmer = 0, corr = 0;
     uint32_t S = 0, hop = 0, cline = 0xffffffffu;
@@ -418,6 +549,10 @@ __global__ __launch_bounds__(256, BRX_LANE_WAVES) void lane_kernel(LaneArgs a)
                         wcnt = 32u - (q & 15u);
                         nextw = a.P[pw + 2];
                         pidx = (uint32_t)pw + 3u;
+                        if (use_mask) {
+                            mw = ((uint32_t)a.M[pw] | ((uint32_t)a.M[pw + 1] << 16)) >> (q & 15u);
+                            nextm = a.M[pw + 2];
+                        }
                         if (d2.w) { // the read's first unit
                             if (n < (uint32_t)k) { // mod.rs:56-58: returned verbatim, i.e. no edits
                                 uint32_t *res = a.u_res + 8ull * u;
@@ -429,6 +564,7 @@ __global__ __launch_bounds__(256, BRX_LANE_WAVES) void lane_kernel(LaneArgs a)
                             } else {
                                 kmer = wreg >> (64 - 2 * k);
                                 wreg <<= 2 * k; // k <= 31
+                                mw >>= k;
                                 wcnt -= (uint32_t)k;
                                 i = (uint32_t)k;
                                 S = 1u << S_FIRST; // previous = get(kmer), mod.rs:67: SCAN that probes kmer itself; prev = false accepts it
@@ -450,8 +586,11 @@ __global__ __launch_bounds__(256, BRX_LANE_WAVES) void lane_kernel(LaneArgs a)
         if (act) {
             if (wcnt <= 16u) { // (the dword was loaded at the refill before this one)
                 wreg |= (uint64_t)nextw << (32u - 2u * wcnt);
+                mw |= nextm << wcnt;
                 wcnt += 16u;
                 nextw = a.P[pidx];
+                if (use_mask)
+                    nextm = a.M[pidx];
                 pidx++;
             }
             const uint32_t cw = (uint32_t)(wreg >> 48); // seq[i .. i+8), first base in bits 15:14
@@ -470,11 +609,14 @@ __global__ __launch_bounds__(256, BRX_LANE_WAVES) void lane_kernel(LaneArgs a)
             pk = is1 ? ((pk & ~3ull) | (uint64_t)cur) : pk;
             // a base accepted behind a fix is known solid (it was a look-ahead of the winning scenario); a tie-break
             // that cannot read one base more is false without a probe (exist/mod.rs:54)
-            const bool need = !(is0 && skip != 0u) && !(is3 && !(rem > c + off + 1u));
+            // SCAN over the read's own bases: the answer is in the mask
+            const uint32_t dirty = (S >> S_DIRTY) & 63u;
+            const bool clean = use_mask && is0 && !first && skip == 0u && dirty == 0u && !slow && hop == 0u;
+            const bool need = !(is0 && skip != 0u) && !(is3 && !(rem > c + off + 1u)) && !clean;
             ev |= need ? 1u : 0u;
 
             // ---- KmerSet::get -------------------------------------------------------------------------------------------
-            bool sol = is0 && !need, unres = false;
+            bool sol = clean ? (mw & 1u) != 0u : (is0 && !need), unres = false;
             // SCAN asks about TWO positions when it can: add(pk, seq[i+1]) shares its reverse complement and all but one of its
             // minimizer windows with pk, and two k-mers in three share their index line -- then the second answer comes out
             // of the line already in hand, and a round moves the scan two bases.  Not across the unit's target, not behind a
@@ -594,13 +736,29 @@ __global__ __launch_bounds__(256, BRX_LANE_WAVES) void lane_kernel(LaneArgs a)
                 const uint32_t jj1 = (is2 && !s_over) ? jj + 1u : 0u;
                 const uint32_t accn = (trig || to_more) ? 0u : acc1, passn = to_scen ? 0u : pass1;
                 const uint32_t skipn = accept ? (skip ? skip - 1u : 0u) : ((fix && !jump) ? c : skip);
+                // a clean SCAN takes the whole run of equal answers (all solid, or all not: `previous` ends as the run's
+                // answer either way), as far as the window, the target and a 64-bit shift of the k-mer allow
+                uint32_t run = 1u;
+                if (clean) {
+                    const uint32_t same = (mw & 1u) ? ~mw : mw;
+                    run = same ? (uint32_t)__builtin_ctz(same) : 32u;
+                    const uint32_t room_t = tgt - i;
+                    run = run < MASK_STEP ? run : MASK_STEP;
+                    run = run < room_t ? run : room_t;
+                    run = run < wcnt ? run : wcnt;
+                }
                 const uint32_t prevn = accept ? (acceptB ? (sol2 ? 1u : 0u) : solb) : (fail ? 0u : (apply_b ? 1u : (prev ? 1u : 0u)));
-                S = st1 | (cur1 << S_CUR) | (jj1 << S_JJ) | (accn << S_ACC) | (passn << S_PASS) | (skipn << S_SKIP) | (prevn << S_PREV);
+                const uint32_t adv = accept ? (first ? 0u : (clean ? run : (acceptB ? 2u : 1u))) : (fail ? 1u : (fix ? used + (jump ? c : 0u) : 0u));
+                // positions ahead whose k-mers hold a corrected base: k - 1 behind a fix (its jump taken off)
+                const uint32_t kd = (uint32_t)k - 1u, jd = jump ? c : 0u;
+                const uint32_t dirtyn = fix ? (kd > jd ? kd - jd : 0u) : ((accept || fail) ? (dirty > adv ? dirty - adv : 0u) : dirty);
+                S = st1 | (cur1 << S_CUR) | (jj1 << S_JJ) | (accn << S_ACC) | (passn << S_PASS) | (skipn << S_SKIP) | (prevn << S_PREV) |
+                    (dirtyn << S_DIRTY);
                 // the k-mers: a failed fix copies the trigger base through and keeps it in the k-mer (mod.rs:91-96)
                 const uint64_t kfix = jump ? (((corr << (2u * c)) | (uint64_t)cb) & mask) : corr;
-                kmer = accept ? (acceptB ? pk2 : pk) : (fail ? ((corr & ~3ull) | (uint64_t)c0) : (fix ? kfix : kmer));
+                const uint64_t krun = ((kmer << (2u * run)) | (wreg >> (64u - 2u * run))) & mask; // (run >= 1)
+                kmer = accept ? (clean ? krun : (acceptB ? pk2 : pk)) : (fail ? ((corr & ~3ull) | (uint64_t)c0) : (fix ? kfix : kmer));
                 corr = trigA ? pk : (trigB ? pk2 : (to_scen ? ((corr & ~3ull) | (uint64_t)win) : corr));
-                const uint32_t adv = accept ? (first ? 0u : (acceptB ? 2u : 1u)) : (fail ? 1u : (fix ? used + (jump ? c : 0u) : 0u));
                 ev |= (trig ? 2u : 0u) | (fix ? 4u : 0u);
                 if (apply_b) { // mod.rs:75-89: one base out, `used` bases of the read consumed -- the lane's only output
                     if (room) {
@@ -614,6 +772,7 @@ __global__ __launch_bounds__(256, BRX_LANE_WAVES) void lane_kernel(LaneArgs a)
                 }
                 i += adv;
                 wreg <<= 2u * adv;
+                mw >>= adv;
                 wcnt -= adv;
             }
         }
@@ -715,7 +874,7 @@ __global__ __launch_bounds__(256) void succ_build_kernel(PassParams p, uint64_t 
 // walk needs the exact rule (a late detection could run past its end): its <= 31 steps are kept as 2-bit codes in a
 // register and every earlier k-mer is rebuilt from them for the comparison; longer gaps go back to the group kernel.
 // What a fix writes: an entry (position, bases of the read consumed, bases written) and the written bases, 16 per word.
-enum { W_ST = 0, W_CUR = 3, W_JJ = 5, W_ACC = 8, W_PASS = 12, W_MODE = 15, W_HITEND = 17, W_SKIP = 24, W_PREV = 27, W_FIRST = 28, W_SLOW = 29 };
+enum { W_ST = 0, W_CUR = 3, W_JJ = 5, W_ACC = 8, W_PASS = 12, W_MODE = 15, W_HITEND = 17, W_DIRTY = 18, W_SKIP = 24, W_PREV = 27, W_FIRST = 28, W_SLOW = 29, W_ECLEAN = 30 };
 enum { WS_SCAN = 0, WS_ALTS = 1, WS_SCEN = 2, WS_MORE = 3, WS_ERRLEN = 4, WS_WALK = 5, WS_WALK4 = 6 };
 enum { WM_GRAPH = 0, WM_ONE = 1, WM_INSSUB = 2 };
 // waves per SIMD the walking automata are compiled for: Graph needs 89 registers, GapSize (its One branch and the exact
@@ -740,6 +899,12 @@ __global__ __launch_bounds__(256, walk_waves(M)) void lane_walk_kernel(LaneArgs 
     uint64_t eat = 0;
     uint64_t wreg = 0, wsave = 0;
     uint32_t wcnt = 0, nextw = 0, pidx = 0, wcnt_s = 0, nextw_s = 0, pidx_s = 0, pbase = 0;
+    // the solidity of the ORIGINAL k-mers that end at the window's positions (lane_mask_kernel; lane_kernel has the
+    // same): bit j of mw for position i + j, the next 16 in the low half of nextm (the high half: the copy kept at a
+    // trigger, beside mw_s).  SCAN reads clean stretches off it, and error_len -- whose k-mers are all original when the
+    // trigger was clean -- the distance to the next solid one.
+    const bool use_mask = a.M != nullptr;
+    uint32_t mw = 0, mw_s = 0, nextm = 0;
     uint64_t kmer = 0, corr = 0, wk = 0, fc = 0, tort = 0; // tort: Brent's tortoise (Graph) / the walked bases (GapSize)
     uint32_t S = 0, hop = 0, cline = 0xffffffffu;
     uint64_t csucc = 0; // the successor bytes of the line held in LDS
@@ -827,6 +992,10 @@ __global__ __launch_bounds__(256, walk_waves(M)) void lane_walk_kernel(LaneArgs 
                         wcnt = 32u - (q & 15u);
                         nextw = a.P[pw + 2];
                         pidx = (uint32_t)pw + 3u;
+                        if (use_mask) {
+                            mw = ((uint32_t)a.M[pw] | ((uint32_t)a.M[pw + 1] << 16)) >> (q & 15u);
+                            nextm = a.M[pw + 2];
+                        }
                         if (d2.w) {
                             if (n < (uint32_t)k) {
                                 uint32_t *res = a.u_res + 8ull * u;
@@ -838,6 +1007,7 @@ __global__ __launch_bounds__(256, walk_waves(M)) void lane_walk_kernel(LaneArgs 
                             } else {
                                 kmer = wreg >> (64 - 2 * k);
                                 wreg <<= 2 * k;
+                                mw >>= k;
                                 wcnt -= (uint32_t)k;
                                 i = (uint32_t)k;
                                 S = 1u << W_FIRST;
@@ -858,8 +1028,11 @@ __global__ __launch_bounds__(256, walk_waves(M)) void lane_walk_kernel(LaneArgs 
         if (act) {
             if (wcnt <= 16u) {
                 wreg |= (uint64_t)nextw << (32u - 2u * wcnt);
+                mw |= (nextm & 0xffffu) << wcnt;
                 wcnt += 16u;
                 nextw = a.P[pidx];
+                if (use_mask)
+                    nextm = (nextm & 0xffff0000u) | a.M[pidx];
                 pidx++;
             }
             const uint32_t st = S & 7u, cur = (S >> W_CUR) & 3u, jj = (S >> W_JJ) & 7u, skip = (S >> W_SKIP) & 7u;
@@ -884,11 +1057,15 @@ __global__ __launch_bounds__(256, walk_waves(M)) void lane_walk_kernel(LaneArgs 
             pk = is_alts ? ((pk & ~3ull) | (uint64_t)cur) : (is_walk ? (((pk << 2) & mask) | (uint64_t)cur) : pk);
             // error_len stops without a probe where the read ends (mod.rs:137-139)
             const bool el_end = is_errlen && elen + 1u >= rem;
-            const bool need = !(is_scan && skip != 0u) && !(is_more && !(rem > c + off + 1u)) && !el_end;
+            // SCAN over the read's own bases, and error_len behind a trigger that was: the answer is in the mask
+            const uint32_t dirty = (S >> W_DIRTY) & 63u;
+            const bool masked = use_mask && !slow && hop == 0u &&
+                                ((is_scan && !first && skip == 0u && dirty == 0u) || (is_errlen && ((S >> W_ECLEAN) & 1u)));
+            const bool need = !(is_scan && skip != 0u) && !(is_more && !(rem > c + off + 1u)) && !el_end && !masked;
             ev |= need ? 1u : 0u;
 
             // ---- KmerSet::get -------------------------------------------------------------------------------------------
-            bool sol = is_scan && !need, unres = false;
+            bool sol = masked ? (mw & 1u) != 0u : (is_scan && !need), unres = false;
             uint32_t slot = 7u; // the slot of the line the k-mer was found in (7: not in a line's slot)
             if (IDX) {
                 uint64_t key;
@@ -937,10 +1114,25 @@ __global__ __launch_bounds__(256, walk_waves(M)) void lane_walk_kernel(LaneArgs 
                 const uint32_t acc = (S >> W_ACC) & 15u, passm = (S >> W_PASS) & 7u;
                 const bool hit_end0 = (S >> W_HITEND) & 1u;
                 const bool accept = is_scan && (sol || !prev), trig = is_scan && !accept; // mod.rs:73, :99-102
+                // masked rounds take a whole run: SCAN the positions with the same answer (`previous` ends as that answer),
+                // error_len the positions that are not solid -- as far as the window, the unit's target (SCAN) and the end
+                // of the read (error_len stops there without a probe, mod.rs:137-139) allow
+                uint32_t run = 1u;
+                if (masked) {
+                    const uint32_t same = (mw & 1u) ? ~mw : mw;
+                    run = same ? (uint32_t)__builtin_ctz(same) : 32u;
+                    const uint32_t lim_r = is_scan ? tgt - i : rem - 1u - elen; // (error_len: >= 1 unless el_end)
+                    run = run < MASK_STEP ? run : MASK_STEP;
+                    run = run < lim_r ? run : lim_r;
+                    run = run < wcnt ? run : wcnt;
+                    run = run ? run : 1u;
+                }
+                const uint64_t krun = (((is_scan ? kmer : wk) << (2u * run)) | (wreg >> (64u - 2u * run))) & mask;
                 // error_len (mod.rs:130-152): the first solid k-mer behind the trigger, or the end of the read
                 const bool el_found = is_errlen && !el_end && sol;
                 const bool el_done = el_end || el_found;
-                const uint32_t elen1 = is_errlen ? elen + 1u : elen; // j of this iteration
+                const bool el_run = is_errlen && masked && !sol && !el_end; // a run of k-mers that are not solid
+                const uint32_t elen1 = is_errlen ? elen + (el_run ? run : 1u) : elen; // j of this iteration (of its last step)
                 const uint32_t mode_new = M == BRX_GRAPH ? (uint32_t)WM_GRAPH
                                                          : (elen1 < (uint32_t)k ? (uint32_t)WM_GRAPH : (elen1 == (uint32_t)k ? (uint32_t)WM_ONE : (uint32_t)WM_INSSUB)); // gap_size.rs:97-108
                 // a graph walk towards a k-mer that is not solid can only end in None (see above)
@@ -1061,8 +1253,17 @@ __global__ __launch_bounds__(256, walk_waves(M)) void lane_walk_kernel(LaneArgs 
                 const uint32_t prevn = accept ? solb : (fail ? 0u : ((fix_one || fix_walk) ? 1u : (prev ? 1u : 0u)));
                 const uint32_t moden = el_done ? mode_new : mode;
                 const uint32_t hitn = el_done ? (el_end ? 1u : 0u) : (hit_end0 ? 1u : 0u);
+                // positions ahead whose k-mers hold a corrected base.  One's fix: k - 1 (its jump taken off).  A finished
+                // Graph walk ends ON first_correct_kmer, the k-mer error_len found: what was dirty in front of the trigger
+                // is as dirty behind it, less the bases passed.  GapSize's fixed-length walk ends on a walked k-mer: k - 1.
+                const bool clean_scan = is_scan && masked;
+                const uint32_t kd = (uint32_t)k - 1u, jd = jump ? c : 0u;
+                const uint32_t passed = accept ? (first ? 0u : (clean_scan ? run : 1u)) : (fail ? 1u : (fix_walk ? used_walk : 0u));
+                const uint32_t dirtyn = fix_one ? (kd > jd ? kd - jd : 0u)
+                                                : ((fix_walk && mode == (uint32_t)WM_INSSUB) ? kd : (dirty > passed ? dirty - passed : 0u));
+                const uint32_t ecleann = trig ? (masked ? 1u : 0u) : ((S >> W_ECLEAN) & 1u);
                 S = st1 | (cur1 << W_CUR) | (jj1 << W_JJ) | (accn << W_ACC) | (passn << W_PASS) | (moden << W_MODE) | (hitn << W_HITEND) |
-                    (skipn << W_SKIP) | (prevn << W_PREV);
+                    (dirtyn << W_DIRTY) | (skipn << W_SKIP) | (prevn << W_PREV) | (ecleann << W_ECLEAN);
                 // Brent's tortoise (Graph) / the walked bases (GapSize's fixed-length walk)
                 if (to_walk) {
                     tort = mode == (uint32_t)WM_GRAPH ? corr_alt : 0ull;
@@ -1083,8 +1284,8 @@ __global__ __launch_bounds__(256, walk_waves(M)) void lane_walk_kernel(LaneArgs 
                 fc = el_done ? (el_end ? wk : pk) : fc;
                 // the k-mers
                 const uint64_t kfix = jump ? (((corr << (2u * c)) | (uint64_t)cb) & mask) : corr;
-                kmer = accept ? pk : (fail ? ((corr & ~3ull) | (uint64_t)(trig ? c0 : c0s)) : (fix_one ? kfix : (fix_walk ? nk : kmer)));
-                wk = trig ? pk : ((is_errlen && !el_done) ? pk : (to_walk ? corr_alt : (step_ok ? nk : wk)));
+                kmer = accept ? (clean_scan ? krun : pk) : (fail ? ((corr & ~3ull) | (uint64_t)(trig ? c0 : c0s)) : (fix_one ? kfix : (fix_walk ? nk : kmer)));
+                wk = trig ? pk : ((is_errlen && !el_done) ? (el_run ? krun : pk) : (to_walk ? corr_alt : (step_ok ? nk : wk)));
                 corr = trig ? pk : (alts_ok ? corr_alt : corr);
                 ev |= trig ? 2u : 0u;
                 // ---- the window ---------------------------------------------------------------------------------------------------
@@ -1096,6 +1297,8 @@ __global__ __launch_bounds__(256, walk_waves(M)) void lane_walk_kernel(LaneArgs 
                     wcnt_s = wcnt;
                     nextw_s = nextw;
                     pidx_s = pidx;
+                    mw_s = mw;
+                    nextm = (nextm & 0xffffu) | (nextm << 16);
                 }
                 const bool back = fail || fix_one; // back to i0, then forward
                 if (back) {
@@ -1103,8 +1306,11 @@ __global__ __launch_bounds__(256, walk_waves(M)) void lane_walk_kernel(LaneArgs 
                     wcnt = wcnt_s;
                     nextw = nextw_s;
                     pidx = pidx_s;
+                    mw = mw_s;
+                    nextm = (nextm & 0xffff0000u) | (nextm >> 16);
                 }
-                uint32_t adv = accept ? (first ? 0u : 1u) : ((trig || (is_errlen && !el_end)) ? 1u : (fail ? 1u : (fix_one ? used_one + (jump ? c : 0u) : 0u)));
+                uint32_t adv = accept ? (first ? 0u : (clean_scan ? run : 1u))
+                                      : (trig ? 1u : ((is_errlen && !el_end) ? (el_run ? run : 1u) : (fail ? 1u : (fix_one ? used_one + (jump ? c : 0u) : 0u))));
                 const uint32_t iadv = accept ? adv : (fail ? 1u : (fix_one ? adv : (fix_walk ? used_walk : 0u)));
                 i += iadv;
                 if (fix_walk && mode == (uint32_t)WM_INSSUB) {
@@ -1114,9 +1320,14 @@ __global__ __launch_bounds__(256, walk_waves(M)) void lane_walk_kernel(LaneArgs 
                     wcnt = 32u - (i & 15u);
                     nextw = a.P[pw + 2];
                     pidx = pw + 3u;
+                    if (use_mask) {
+                        mw = ((uint32_t)a.M[pw] | ((uint32_t)a.M[pw + 1] << 16)) >> (i & 15u);
+                        nextm = (nextm & 0xffff0000u) | a.M[pw + 2];
+                    }
                     adv = 0;
                 }
                 wreg <<= 2u * adv;
+                mw >>= adv;
                 wcnt -= adv;
             }
         }
@@ -1664,6 +1875,7 @@ __global__ __launch_bounds__(256) void lane_apply_walk_kernel(LaneArgs a)
 
 struct LaneWork {
     uint32_t *nu = nullptr, *u_read = nullptr, *u_q = nullptr, *u_res = nullptr, *fail_list = nullptr, *P = nullptr;
+    uint16_t *M = nullptr;
     UnitDesc *u_desc = nullptr;
     uint4 *u_in = nullptr;
     uint32_t *E[MAX_DEPTH] = {nullptr, nullptr, nullptr};
@@ -1702,15 +1914,15 @@ void launch_lane_walk(const LaneArgs &a, uint32_t blocks, hipStream_t s)
         lane_walk_kernel<IDX, 0, M><<<blocks, 256, 0, s>>>(a);
 }
 
-template <bool IDX>
+template <bool IDX, bool MASK>
 void launch_lane(const LaneArgs &a, uint32_t blocks, hipStream_t s)
 {
     if (a.p.k == 19)
-        lane_kernel<IDX, 19><<<blocks, 256, 0, s>>>(a);
+        lane_kernel<IDX, 19, MASK><<<blocks, 256, 0, s>>>(a);
     else if (a.p.k == 21)
-        lane_kernel<IDX, 21><<<blocks, 256, 0, s>>>(a);
+        lane_kernel<IDX, 21, MASK><<<blocks, 256, 0, s>>>(a);
     else
-        lane_kernel<IDX, 0><<<blocks, 256, 0, s>>>(a);
+        lane_kernel<IDX, 0, MASK><<<blocks, 256, 0, s>>>(a);
 }
 
 } // namespace
@@ -1722,7 +1934,7 @@ void lane_ws_free(brx_chain *ch)
     LaneWork *w = (LaneWork *)ch->lane_ws;
     if (!w)
         return;
-    for (void *q : {(void *)w->u_in, (void *)w->u_desc, (void *)w->nu, (void *)w->u_read, (void *)w->u_q, (void *)w->u_res, (void *)w->fail_list, (void *)w->P,
+    for (void *q : {(void *)w->u_in, (void *)w->u_desc, (void *)w->nu, (void *)w->u_read, (void *)w->u_q, (void *)w->u_res, (void *)w->fail_list, (void *)w->P, (void *)w->M,
                     (void *)w->E[0], (void *)w->E[1], (void *)w->E[2], (void *)w->BW[0], (void *)w->BW[1], (void *)w->BW[2], (void *)w->ubase,
                     (void *)w->u_qk})
         if (q)
@@ -1802,6 +2014,7 @@ int lane_pass(brx_chain *ch, const PassParams &p, const LanePassInfo &info, hipS
         w->p_cap = 0; // (a growth that fails half-way leaves freed pointers: nothing here may be trusted then)
         const uint64_t cap = p_bound + p_bound / 16;
         BRX_TRY(grow_dev((void **)&w->P, cap * 4));
+        BRX_TRY(grow_dev((void **)&w->M, cap * 2));
         w->p_cap = cap;
     }
     if (w->e_cap < e_bound) {
@@ -1835,6 +2048,15 @@ int lane_pass(brx_chain *ch, const PassParams &p, const LanePassInfo &info, hipS
     a.u_desc = w->u_desc;
     a.u_in = w->u_in;
     a.P = w->P;
+    // BRX_LANE_MASK: the solidity mask of the original k-mers (lane_mask_kernel) -- 0: never, every SCAN / error_len
+    // position is probed; 1: for the walking correctors, whose error_len it shortens to a bit scan (rounds 1.97 G -> 0.96 G
+    // per Gbp for Graph; both launches 65.0 -> 52.6 ms with 10.2 ms of mask kernel to pay for it; BASELINE configs[4]'s
+    // share, 2^28 index lines: 6.58 -> 7.13 Gbases/s on one box); 2: for One as well (there the mask kernel costs what the
+    // shorter scan saves: rounds 1.24 G -> 0.59 G, launch 16 -> 12 ms, mask 8.7 ms).  Either way the index lines fetched
+    // are the same ones: the mask kernel fetches them for 64 neighbouring positions at a time instead of lane by lane.
+    const uint32_t mask_mode = env_u32("BRX_LANE_MASK", 1u);
+    const bool use_mask = walk ? mask_mode >= 1u : mask_mode >= 2u;
+    a.M = use_mask ? w->M : nullptr;
     for (int d = 0; d < MAX_DEPTH; d++) {
         a.E[d] = w->E[d];
         a.EW[d] = reinterpret_cast<uint2 *>(w->E[d]); // (8-byte entries at half the index: the same bytes)
@@ -1877,11 +2099,24 @@ int lane_pass(brx_chain *ch, const PassParams &p, const LanePassInfo &info, hipS
         const uint32_t grid = p.n_reads < (1u << 16) ? p.n_reads : (1u << 16);
         lane_pack_kernel<<<grid, 256, 0, s>>>(a);
     }
+    if (use_mask) {
+        KernelTimer t("lane_mask", s);
+        BRX_HIP(hipMemsetAsync(w->M, 0, p_bound * 2ull, s)); // (the padding behind every read: no solid k-mers there)
+        const uint64_t waves = units_bound < 256ull * 32ull ? units_bound : 256ull * 32ull;
+        const uint32_t blocks = (uint32_t)((waves + 3) / 4);
+        if (idx)
+            lane_mask_kernel<true><<<blocks, 256, 0, s>>>(a);
+        else
+            lane_mask_kernel<false><<<blocks, 256, 0, s>>>(a);
+    }
     {
         KernelTimer t("lane_sync", s);
         const uint64_t waves = units_bound < 256ull * 32ull ? units_bound : 256ull * 32ull;
         const uint32_t blocks = (uint32_t)((waves + 3) / 4);
-        if (idx)
+        if (use_mask) {
+            const uint64_t ub = (units_bound + 255ull) / 256ull;
+            lane_sync_mask_kernel<<<(uint32_t)(ub < 16384ull ? ub : 16384ull), 256, 0, s>>>(a);
+        } else if (idx)
             lane_sync_kernel<true><<<blocks, 256, 0, s>>>(a);
         else
             lane_sync_kernel<false><<<blocks, 256, 0, s>>>(a);
@@ -1892,13 +2127,17 @@ int lane_pass(brx_chain *ch, const PassParams &p, const LanePassInfo &info, hipS
         static const char *names[5] = {"correct_pass", "correct_pass_two", "correct_pass_graph", "correct_pass_greedy", "correct_pass_gap_size"};
         KernelTimer t(names[info.method], s);
         const uint64_t want = (units_bound + 255ull) / 256ull;
-        const uint64_t waves = walk ? (uint64_t)walk_waves(info.method) : (uint64_t)BRX_LANE_WAVES;
+        const uint64_t waves = walk ? (uint64_t)walk_waves(info.method) : (use_mask ? 6ull : (uint64_t)BRX_LANE_WAVES);
         const uint32_t blocks = (uint32_t)(want < 256ull * waves ? want : 256ull * waves);
         if (info.method == BRX_ONE) {
-            if (idx)
-                launch_lane<true>(a, blocks, s);
+            if (idx && use_mask)
+                launch_lane<true, true>(a, blocks, s);
+            else if (idx)
+                launch_lane<true, false>(a, blocks, s);
+            else if (use_mask)
+                launch_lane<false, true>(a, blocks, s);
             else
-                launch_lane<false>(a, blocks, s);
+                launch_lane<false, false>(a, blocks, s);
         } else if (info.method == BRX_GRAPH) {
             if (idx)
                 launch_lane_walk<true, BRX_GRAPH>(a, blocks, s);

@@ -17,8 +17,8 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture
 def lane_env(monkeypatch):
-    def set_(chunk=None, sync=None, lane=None):
-        for key, v in (("BRX_LANE_CHUNK", chunk), ("BRX_LANE_SYNC", sync), ("BRX_LANE", lane)):
+    def set_(chunk=None, sync=None, lane=None, mask=None):
+        for key, v in (("BRX_LANE_CHUNK", chunk), ("BRX_LANE_SYNC", sync), ("BRX_LANE", lane), ("BRX_LANE_MASK", mask)):
             if v is None:
                 monkeypatch.delenv(key, raising=False)
             else:
@@ -59,11 +59,13 @@ def test_lane_off_is_the_group_kernel(raw_reads, solid_fixture_bytes, lane_env):
     assert chain2.last_stats()["lane_units"] > 0 and a == b
 
 
+@pytest.mark.parametrize("mask", [None, 2])
 @pytest.mark.parametrize("k,confirm", [(13, 5), (15, 2), (19, 5), (19, 0), (21, 3), (25, 1)])
-def test_synthetic_reads_vs_oracle(lane_env, k, confirm):
+def test_synthetic_reads_vs_oracle(lane_env, k, confirm, mask):
     """synthetic ONT-error reads (the bench's error model) against a counted set: dense / lazy / sparse holdings of the set
-    behind the same automaton, confirm 0 ... 5, short reads, reads shorter than k, an empty read"""
-    lane_env(128, 3)
+    behind the same automaton, confirm 0 ... 5, short reads, reads shorter than k, an empty read; mask = 2: One too scans
+    the stretches without a fix off the solidity mask of the original k-mers (BRX_LANE_MASK, off for One by default)"""
+    lane_env(128, 3, mask=mask)
     cfg = synth.config(genome_len=40_000, read_len=3_000)
     g = synth.genome_host(cfg)
     bases, offs = synth.reads_host(cfg, g, 0, 500)
@@ -124,13 +126,14 @@ def test_growing_reads_and_slot_overflow(lane_env):
 
 
 # ---------------------------------------------------------------- Graph / GapSize in lane form ----------------
-@pytest.mark.parametrize("chunk,sync", [(64, 1), (100, 4), (333, 2), (None, None)])
+@pytest.mark.parametrize("chunk,sync,mask", [(64, 1, None), (100, 4, 0), (333, 2, 2), (None, None, None), (None, None, 0)])
 @pytest.mark.parametrize("names", [["graph"], ["gap_size"], ["one", "graph", "gap_size"]])
-def test_walking_correctors_any_chunking(raw_reads, solid_fixture_bytes, lane_env, chunk, sync, names):
+def test_walking_correctors_any_chunking(raw_reads, solid_fixture_bytes, lane_env, chunk, sync, mask, names):
     """correct::Graph / correct::GapSize forward passes as lane automata (error_len, alt_nucs, the unique-successor walk
     with Brent's detector / the exact visited rule, GapSize's three-way dispatch): raw.fasta against the reference's
-    fixture set, forward only and forward + reverse, any chunk length / sync rule"""
-    lane_env(chunk, sync)
+    fixture set, forward only and forward + reverse, any chunk length / sync rule; with the solidity mask of the original
+    k-mers (the default for these: clean stretches and error_len are read off it), without (mask = 0), and for One too (2)"""
+    lane_env(chunk, sync, mask=mask)
     reads = raw_reads[:50]
     gs = br_amd.Pcon.from_pcon_solid(solid_fixture_bytes)
     ref = O.Solid.from_bytes(solid_fixture_bytes)
@@ -156,10 +159,12 @@ def test_walk_lane_off_is_the_group_kernel(raw_reads, solid_fixture_bytes, monke
     assert chain2.last_stats()["lane_units"] > 0 and a == b
 
 
+@pytest.mark.parametrize("mask", [None, 0])
 @pytest.mark.parametrize("k,method", [(13, "graph"), (13, "gap_size"), (19, "graph"), (19, "gap_size"), (21, "graph"), (21, "gap_size")])
-def test_walking_correctors_synthetic(lane_env, k, method):
-    """the bench's error model against counted sets: bit vector (k = 13), lazy bits + index (19), sparse chained index (21)"""
-    lane_env(128, 3)
+def test_walking_correctors_synthetic(lane_env, k, method, mask):
+    """the bench's error model against counted sets: bit vector (k = 13), lazy bits + index (19), sparse chained index (21);
+    with the solidity mask (default) and without"""
+    lane_env(128, 3, mask=mask)
     cfg = synth.config(genome_len=40_000, read_len=3_000)
     g = synth.genome_host(cfg)
     bases, offs = synth.reads_host(cfg, g, 0, 400)

@@ -2,7 +2,8 @@
 """Randomised differential test: the HIP correctors against the CPU oracle on small random jobs with odd shapes
 (k, confirm, max_search, abundance, read lengths around k, error rates, method chains, group widths, index on/off,
 sparse/lazy sets).  Prints one line per case and exits non-zero at the first mismatch.
-usage: python tools/fuzz_parity.py [seconds=120] [seed=1]"""
+usage: python tools/fuzz_parity.py [seconds=120] [seed=1] [only_case=0]
+(only_case: replay that case of the seed's sequence alone -- the cases before it are generated and skipped)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -13,6 +14,8 @@ from oracle import oracle as O
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+only_case = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+repeat = int(sys.argv[4]) if len(sys.argv) > 4 else 1  # (with only_case: run the case this many times -- rare races)
 rng = np.random.default_rng(seed)
 METHODS = ["one", "two", "graph", "greedy", "gap_size"]
 ALPHA = np.frombuffer(b"ACGT", dtype=np.uint8)
@@ -77,7 +80,9 @@ while time.time() < t_end:
            "BRX_LANE": str(rng.choice(["", "", "", "0"])), "BRX_LANE_CHUNK": str(rng.choice(["", "64", "100", "333"])),
            "BRX_LANE_SYNC": str(rng.choice(["", "1", "2", "8"])), "BRX_LANE_WALK": str(rng.choice(["", "", "", "0"])),
            # level 1 of the partitioned build: blocks that take many tiles each even on small inputs
-           "BRX_L1_GRID": str(rng.choice(["", "", "1", "5"]))}
+           "BRX_L1_GRID": str(rng.choice(["", "", "1", "5"])),
+           # the solidity mask of the original k-mers: off / walking correctors (default) / One as well
+           "BRX_LANE_MASK": str(rng.choice(["", "0", "2", "2"]))}
     for key, v in env.items():
         if v == "":
             os.environ.pop(key, None)
@@ -92,9 +97,14 @@ while time.time() < t_end:
     if strategy == _lib.COUNT_DENSE:
         os.environ["BRX_FORCE_SPARSE"] = "0"
     counted = [r for r in reads]
+    batch = int(rng.choice([3, 50, 8192])) if continue_presence else 0
+    if only_case and case != only_case:
+        if case > only_case:
+            break
+        continue
     if continue_presence:
         a = 0
-        gs = br_amd.Pcon.from_fasta(counted, k, batch=int(rng.choice([3, 50, 8192])))
+        gs = br_amd.Pcon.from_fasta(counted, k, batch=batch)
     else:
         cnt = br_amd.Counter(k, 0, strategy)
         if counted:
@@ -105,14 +115,30 @@ while time.time() < t_end:
     if gs.popcount() != ref.popcount():
         print("SET MISMATCH", desc); sys.exit(1)
     om = O.build_methods(ref, names, c, ms)
+    for again in range(repeat - 1 if only_case else 0):
+        # the whole job again, set build included (allocations, atomics and timing differ from run to run)
+        cnt2 = br_amd.Counter(k, 0, strategy)
+        if counted:
+            cnt2.add_reads(counted)
+        gs2 = cnt2.finish(a) if not continue_presence else br_amd.Pcon.from_fasta(counted, k, batch=batch)
+        got2 = br_amd.Chain(gs2, [(m, c, ms) for m in names], two_side=two_side).correct_reads(reads)
+        bad = [ri for ri, (r, g_) in enumerate(zip(reads, got2)) if g_ != O.correct_record(om, r, two_side)]
+        if gs2.popcount() != ref.popcount() or bad:
+            print("REPEAT MISMATCH at repetition", again, "set", gs2.popcount(), ref.popcount(), "reads", bad[:10])
+            for ri in bad[:3]:
+                print(" read", ri, len(reads[ri]), reads[ri][:600], "\n want", O.correct_record(om, reads[ri], two_side)[:600], "\n got ", got2[ri][:600])
     try:
         got = br_amd.Chain(gs, [(m, c, ms) for m in names], two_side=two_side).correct_reads(reads)
     except _lib.BrxError as e:
         if "does not terminate" in str(e):   # greedy can spin in the reference too: not comparable
             print("skip (non-terminating greedy)", desc); continue
         print("ERROR", e, desc); sys.exit(1)
-    for r, g_ in zip(reads, got):
-        if g_ != O.correct_record(om, r, two_side):
-            print("READ MISMATCH", desc, "\nread:", r[:200]); sys.exit(1)
+    for ri, (r, g_) in enumerate(zip(reads, got)):
+        want = O.correct_record(om, r, two_side)
+        if g_ != want:
+            print("READ MISMATCH", desc, "\nread", ri, "of length", len(r), ":", r[:400], "\nwant:", want[:400], "\ngot: ", g_[:400])
+            if only_case:
+                continue
+            sys.exit(1)
     print("ok", desc, flush=True)
 print(f"{case} cases, no mismatch")
