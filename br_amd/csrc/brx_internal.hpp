@@ -37,6 +37,12 @@ void *host_buf_acquire(size_t bytes);
 void host_buf_release(void *p);
 bool host_buf_is_pinned(const void *p);
 
+// device memory through the block pool (brx_devpool.hip); every hipMalloc / hipFree below this header is one of these
+hipError_t dev_alloc(void **out, size_t bytes);
+hipError_t dev_free(void *p);
+void dev_pool_trim();
+size_t dev_pool_bytes();
+
 // BRX_TRACE=1: synchronise `s` and print a time-stamped stage name on stderr (finding where a big job stalls)
 void trace_stage(hipStream_t s, const char *what);
 
@@ -178,3 +184,7 @@ struct brx_chain {
     uint64_t h_in_cap = 0;
     std::mutex mu;
 };
+
+// The library's device memory comes from the block pool (brx_devpool.hip, which does not include this header).
+#define hipMalloc(ptr, bytes) brx::dev_alloc((void **)(ptr), (bytes))
+#define hipFree(ptr) brx::dev_free((void *)(ptr))

@@ -56,6 +56,10 @@ constexpr int MAX_DEPTH = 3;               // edit lists: own stretch + two stre
 constexpr uint32_t MAX_LANE_READ = 1u << 28; // positions are kept in 28 bits of an edit
 constexpr uint32_t AP_EDITS = 512;  // fixes replayed per batch
 constexpr uint32_t AP_PIECES = 256; // pieces (unit, depth) gathered per batch
+#ifndef BRX_AP_BS
+#define BRX_AP_BS 128
+#endif
+constexpr uint32_t AP_BS = BRX_AP_BS; // threads of One's replay kernel per read
 constexpr uint32_t APW_EDITS = 512; // ... by the walking correctors' replay kernel
 constexpr uint32_t AP_VERIFY = 1024; // longest fixed-length walk whose k-mers the replay kernel checks for a repeat
 constexpr uint32_t LANE_GRAB = 64;           // units a wave draws from the global counter at a time
@@ -1357,7 +1361,7 @@ __global__ __launch_bounds__(256, walk_waves(M)) void lane_walk_kernel(LaneArgs 
 // OUTPUT-centric: every thread produces 16 aligned output bytes, finds the fix its first byte lies behind by bisection
 // of the fixes' output offsets (LDS), and in the common case -- no fix inside its 16 bytes -- moves them as one vector.
 
-__global__ __launch_bounds__(256) void lane_apply_kernel(LaneArgs a)
+__global__ __launch_bounds__(AP_BS) void lane_apply_kernel(LaneArgs a)
 {
     const PassParams &p = a.p;
     __shared__ uint32_t e_raw[AP_EDITS];     // the fixes of the batch
@@ -1365,12 +1369,12 @@ __global__ __launch_bounds__(256) void lane_apply_kernel(LaneArgs a)
     __shared__ uint32_t e_in[AP_EDITS];      // input position where that stretch starts
     __shared__ uint64_t pc_src[AP_PIECES];   // pieces: where their fixes are (list index << 60 | entry)
     __shared__ uint32_t pc_off[AP_PIECES + 1]; // ... and how many came before
-    __shared__ uint32_t sh_part[4];
+    __shared__ uint32_t sh_part[AP_BS / 64];
     __shared__ uint32_t sh_np, sh_next_u, sh_state;
     // the records of the read's first 256 units, loaded side by side: the chain is walked by ONE lane, and every
     // dependent trip to global memory it makes is a microsecond the other 255 wait
-    __shared__ uint4 sh_ra[256], sh_rb[256];
-    __shared__ uint64_t sh_eat[256];
+    __shared__ uint4 sh_ra[AP_BS], sh_rb[AP_BS];
+    __shared__ uint64_t sh_eat[AP_BS];
     for (uint32_t r = blockIdx.x; r < p.n_reads; r += gridDim.x) {
         if (p.in_staged && p.in_lens[r] == 0xffffffffu) { // given up by an earlier pass of this attempt: stays poisoned
             if (threadIdx.x == 0)
@@ -1405,7 +1409,7 @@ __global__ __launch_bounds__(256) void lane_apply_kernel(LaneArgs a)
                 uint32_t np = 0, cnt = 0, u = u_next, d = d_next, state = 1; // state: 0 chain done, 1 more to come, 2 failed
                 pc_off[0] = 0;
                 for (;;) {
-                    const bool near = u - ub < 256u;
+                    const bool near = u - ub < AP_BS;
                     const uint4 ra = near ? sh_ra[u - ub] : *reinterpret_cast<const uint4 *>(a.u_res + 8ull * u);
                     const uint4 rb = near ? sh_rb[u - ub] : *reinterpret_cast<const uint4 *>(a.u_res + 8ull * u + 4);
                     const uint32_t res[8] = {ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z, rb.w};
@@ -1422,7 +1426,7 @@ __global__ __launch_bounds__(256) void lane_apply_kernel(LaneArgs a)
                             break;
                         }
                         const uint32_t xu = d == 0 ? u : res[2 * d - 1];
-                        pc_src[np] = ((uint64_t)d << 60) | (xu - ub < 256u ? sh_eat[xu - ub] : edit_start(in_at, r, ub, xu - ub, a.u_q[xu]));
+                        pc_src[np] = ((uint64_t)d << 60) | (xu - ub < AP_BS ? sh_eat[xu - ub] : edit_start(in_at, r, ub, xu - ub, a.u_q[xu]));
                         cnt += ne; // (a single piece may hold more than a batch: it is then replayed in several)
                         np++;
                         pc_off[np] = cnt;
@@ -1454,7 +1458,7 @@ __global__ __launch_bounds__(256) void lane_apply_kernel(LaneArgs a)
             for (uint32_t f0 = 0; f0 < n_all; f0 += AP_EDITS) {
                 const uint32_t nb = n_all - f0 < AP_EDITS ? n_all - f0 : AP_EDITS;
                 __syncthreads();
-                for (uint32_t t = threadIdx.x; t < nb; t += 256) {
+                for (uint32_t t = threadIdx.x; t < nb; t += AP_BS) {
                     const uint32_t f = f0 + t;
                     uint32_t lo = 0, hi = np; // the piece of fix f: pc_off[lo] <= f < pc_off[lo + 1]
                     while (hi - lo > 1u) {
@@ -1469,7 +1473,7 @@ __global__ __launch_bounds__(256) void lane_apply_kernel(LaneArgs a)
                 }
                 __syncthreads();
                 // stretch in front of fix t: from the end of the fix before (cur_in for the first) to its position
-                const uint32_t per = (nb + 255u) / 256u; // consecutive fixes per thread
+                const uint32_t per = (nb + AP_BS - 1u) / AP_BS; // consecutive fixes per thread
                 const uint32_t t0 = threadIdx.x * per, t1 = t0 + per < nb ? t0 + per : nb;
                 uint32_t part = 0;
                 for (uint32_t t = t0; t < t1; t++) {
@@ -1490,7 +1494,9 @@ __global__ __launch_bounds__(256) void lane_apply_kernel(LaneArgs a)
                 uint32_t run = inc - part;
                 for (uint32_t q = 0; q < (threadIdx.x >> 6); q++)
                     run += sh_part[q];
-                const uint32_t batch_total = sh_part[0] + sh_part[1] + sh_part[2] + sh_part[3];
+                uint32_t batch_total = 0;
+                for (uint32_t q = 0; q < AP_BS / 64u; q++)
+                    batch_total += sh_part[q];
                 for (uint32_t t = t0; t < t1; t++) {
                     e_os[t] = run;
                     run += ((e_raw[t] >> 4) - e_in[t]) + 1u;
@@ -1503,7 +1509,7 @@ __global__ __launch_bounds__(256) void lane_apply_kernel(LaneArgs a)
                     uint8_t *ob = dst + total;
                     const uint32_t head = (uint32_t)((16u - (uint32_t)((uintptr_t)ob & 15u)) & 15u);
                     const uint32_t n_chunks = (batch_total + (16u - head) % 16u + 15u) / 16u + 1u;
-                    for (uint32_t ch = threadIdx.x; ch < n_chunks; ch += 256) {
+                    for (uint32_t ch = threadIdx.x; ch < n_chunks; ch += AP_BS) {
                         // chunk 0 = the bytes in front of the first 16-byte boundary
                         const uint32_t x0 = ch == 0 ? 0u : head + 16u * (ch - 1u);
                         uint32_t x1 = ch == 0 ? head : x0 + 16u;
@@ -2156,7 +2162,7 @@ int lane_pass(brx_chain *ch, const PassParams &p, const LanePassInfo &info, hipS
         if (walk)
             lane_apply_walk_kernel<<<grid, 256, 0, s>>>(a);
         else
-            lane_apply_kernel<<<grid, 256, 0, s>>>(a);
+            lane_apply_kernel<<<grid, AP_BS, 0, s>>>(a);
     }
     {
         // the reads the units could not settle (three misses in a row, more fixes than a list holds): the group kernel

@@ -8,7 +8,7 @@ cd "$(dirname "$0")/../br_amd/csrc"
 name=$1; shift
 bdir=build_ab_$name
 mkdir -p $bdir ../lib/ab
-srcs="brx_api brx_set brx_index brx_partbuild brx_scan brx_correct brx_onelane brx_pipeline brx_synth brx_exchange"
+srcs="brx_api brx_set brx_index brx_partbuild brx_scan brx_correct brx_onelane brx_pipeline brx_synth brx_exchange brx_devpool"
 pids=()
 for f in $srcs; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 "$@" -c $f.hip -o $bdir/$f.o &
