@@ -102,6 +102,8 @@ SIGNATURES = {
     "brx_buf_free": (None, [_vp]),
     "brx_host_alloc": (_vp, [C.c_size_t]),
     "brx_host_free": (None, [_vp]),
+    "brx_devpool_trim": (None, []),
+    "brx_devpool_bytes": (C.c_uint64, []),
     "brx_run_correction_fd": (C.c_int, [_vp, C.POINTER(Method), C.c_uint32, C.c_bool, C.c_int, C.c_int, C.c_uint32, _u64p]),
     "brx_count_fasta_fd": (C.c_int, [_vp, C.c_int, C.c_uint32, _u64p]),
     "brx_set_insert_fasta_fd": (C.c_int, [_vp, C.c_int, C.c_uint32, _u64p]),

@@ -301,5 +301,7 @@ void brx_buf_free(void *p) { brx::host_buf_release(p); }
 void *brx_host_alloc(size_t bytes) { return brx::host_buf_acquire(bytes ? bytes : 1); }
 
 void brx_host_free(void *p) { brx::host_buf_release(p); }
+void brx_devpool_trim(void) { brx::dev_pool_trim(); }
+uint64_t brx_devpool_bytes(void) { return (uint64_t)brx::dev_pool_bytes(); }
 
 } // extern "C"

@@ -259,6 +259,13 @@ void brx_buf_free(void *p);
  * brx_host_free (or brx_buf_free: the callee-allocated outputs of the batch entries are the same kind of block).      */
 void *brx_host_alloc(size_t bytes);
 void brx_host_free(void *p);
+/* Device memory of the library is pooled too: blocks of 32 MiB and more are kept when a counter, set or chain is freed
+ * (up to BRX_DEVPOOL_GB GiB per process, default 48; 0 = no pool) and reused by the next one -- the reference builds and
+ * drops its 2^(2k-1)-byte counter table and its set once per run (src/main.rs:60-115), a host that runs job after job
+ * would otherwise pay the driver's unmap / map of gigabytes every time.  brx_devpool_trim gives everything that is parked
+ * back to the runtime (a host that needs the HBM for something else); brx_devpool_bytes says how much that is.            */
+void brx_devpool_trim(void);
+uint64_t brx_devpool_bytes(void);
 
 /* ---- host pipelines over file descriptors ----------------------------------------
  * run_correction (src/lib.rs:22-139) for ONE input/output pair: FASTA records are parsed from in_fd (plain

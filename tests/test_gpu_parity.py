@@ -897,3 +897,24 @@ def test_comm_init_all_one_process():
             assert gs.to_solid_bytes() == ref.to_solid_bytes()
     finally:
         L.brx_comm_free(comms[0])
+
+
+def test_device_block_pool_reuse_and_trim(raw_reads):
+    """Device memory of the library is pooled (brx_devpool.hip): a set built, dropped and built again reuses the parked
+    blocks -- same bytes as the first build --, brx_devpool_trim hands everything parked back, and a third build after that
+    is the same again.  (Blocks under 32 MiB bypass the pool: k = 15's 64 MiB bit vector / 512 MiB counter do not.)"""
+    L = _lib.lib()
+    k, a = 15, 1
+    reads = raw_reads[:60]
+    first = br_amd.Pcon.from_count(reads, k, a, strategy=_lib.COUNT_DENSE).to_solid_bytes()
+    import gc
+    gc.collect()
+    parked = L.brx_devpool_bytes()
+    assert parked >= (1 << 29)          # the dense counter table of k = 15 at least
+    second = br_amd.Pcon.from_count(reads, k, a, strategy=_lib.COUNT_DENSE).to_solid_bytes()
+    assert second == first
+    gc.collect()
+    L.brx_devpool_trim()
+    assert L.brx_devpool_bytes() == 0
+    third = br_amd.Pcon.from_count(reads, k, a, strategy=_lib.COUNT_SORTED).to_solid_bytes()
+    assert third == first
