@@ -16,6 +16,10 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 only_case = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 repeat = int(sys.argv[4]) if len(sys.argv) > 4 else 1  # (with only_case: run the case this many times -- rare races)
+# FUZZ_FOCUS=walklane: every job ends in graph or gap_size with the lane forms on and short chunks (their own random
+# stream, drawn after the case's: the cases of a seed stay what they are without it)
+focus = os.environ.get("FUZZ_FOCUS", "")
+frng = np.random.default_rng(seed + 7919)
 rng = np.random.default_rng(seed)
 METHODS = ["one", "two", "graph", "greedy", "gap_size"]
 ALPHA = np.frombuffer(b"ACGT", dtype=np.uint8)
@@ -83,6 +87,12 @@ while time.time() < t_end:
            "BRX_L1_GRID": str(rng.choice(["", "", "1", "5"])),
            # the solidity mask of the original k-mers: off / walking correctors (default) / One as well
            "BRX_LANE_MASK": str(rng.choice(["", "0", "2", "2"]))}
+    if focus == "walklane":
+        names[-1] = str(frng.choice(["graph", "gap_size"]))
+        env.update({"BRX_LANE": "", "BRX_LANE_WALK": "", "BRX_LANE_CHUNK": str(frng.choice(["64", "100"])),
+                    "BRX_LANE_SYNC": str(frng.choice(["1", "2", "4"])), "BRX_LANE_MASK": str(frng.choice(["", "0", "2"]))})
+        if c > 5 and names[-1] == "gap_size":
+            c = 5
     for key, v in env.items():
         if v == "":
             os.environ.pop(key, None)
