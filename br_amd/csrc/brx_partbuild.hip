@@ -121,7 +121,7 @@ __device__ __forceinline__ bool store_ok(uint64_t idx, uint64_t cap)
 __device__ __forceinline__ bool store_ok(uint64_t, uint64_t) { return true; }
 #endif
 constexpr bool XCD_ITEMS = BRX_XCD_ITEMS != 0;
-constexpr uint32_t L1_TILE = 4096;                    // k-mer start positions per level-1 work item (8192: scatter 5.4 ms, 4096: 4.3, 2048: 5.9 at 1 Gbp -- 35 KB of LDS = 4 blocks per CU)
+constexpr uint32_t L1_TILE = 4096;                    // k-mer start positions per level-1 work item = 16 per thread (round 1: 8192 -> scatter 5.4 ms, 4096 -> 4.3, 2048 -> 5.9 at 1 Gbp; the scatter now stages 16 KB of keys + 10 KB of counters: 5 blocks per CU)
 constexpr uint32_t PACK_WORDS = L1_TILE / 16 + 4;     // bases of the tile + k - 1 + slack, 16 per word
 constexpr uint32_t BND_WORDS = (L1_TILE + 64) / 32 + 2; // read-boundary bitmap of the same window
 
@@ -156,7 +156,7 @@ __device__ __forceinline__ uint64_t kmer_at(const uint32_t *__restrict__ pk, uin
     return val >> (64 - 2 * k);
 }
 
-// ---- which work items a workgroup takes -------------------------------------------------------------------------------------
+// ---- which work items a workgroup takes (levels >= 2; level 1 gives a block a contiguous range: l1_range) ------------
 // Workgroups are dealt round-robin over the 8 XCDs (blocks b and b + 8 share one: MI355X_MICROARCH.md, Workgroup
 // dispatch), and tile t + 1 of a scatter appends each digit's keys right behind tile t's -- 32-byte runs at 8 keys per
 // digit.  With the plain grid-stride loop neighbouring tiles sit on different XCDs, so every 128-byte line of the output
