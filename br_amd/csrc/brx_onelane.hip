@@ -1583,9 +1583,6 @@ __global__ __launch_bounds__(256) void lane_apply_walk_kernel(LaneArgs a)
     __shared__ uint4 sh_rr[512]; // the records of the read's first 256 units: [t] and [256 + t]
     __shared__ uint64_t sh_eat[256];
     uint4 *sh_ra = sh_rr, *sh_rb = sh_rr + 256;
-    uint64_t *vk = reinterpret_cast<uint64_t *>(sh_rr); // (long fixed-length walks only: their k-mers, over the records)
-    __shared__ uint32_t vw[AP_VERIFY / 16 + 4];        // ... their first k-mer and their bases
-    bool records_lost = false;
     const int k_ = p.k;
     const uint64_t kmask_ = kmask(k_);
     for (uint32_t r = blockIdx.x; r < p.n_reads; r += gridDim.x) {
@@ -1617,15 +1614,6 @@ __global__ __launch_bounds__(256) void lane_apply_walk_kernel(LaneArgs a)
         }
         while (more && !failed) {
             __syncthreads();
-            if (records_lost) { // (a long walk's check used the records' memory)
-                if (ub + threadIdx.x < (uint32_t)a.ubase[r + 1]) {
-                    const uint32_t uu = ub + threadIdx.x;
-                    sh_ra[threadIdx.x] = *reinterpret_cast<const uint4 *>(a.u_res + 8ull * uu);
-                    sh_rb[threadIdx.x] = *reinterpret_cast<const uint4 *>(a.u_res + 8ull * uu + 4);
-                }
-                records_lost = false;
-                __syncthreads();
-            }
             if (threadIdx.x == 0) {
                 uint32_t np = 0, cnt = 0, u = u_next, d = d_next, state = 1;
                 pc_off[0] = 0;
@@ -1739,77 +1727,42 @@ __global__ __launch_bounds__(256) void lane_apply_walk_kernel(LaneArgs a)
             // GapSize's fixed-length walks (gap_size.rs:57-85) were not checked for revisits by the lanes: the reference returns
             // None the moment a k-mer of the walk repeats (viewed_kmer, :75-81).  A fix whose gap + 1 k-mers -- its first one
             // and one more per walked base -- hold a repeat would not have been made: the read goes back to the group kernel.
+            // The walk is deterministic -- every k-mer is the unique solid successor of the one before --, so two equal k-mers
+            // x_a = x_b drag everything behind them along: x_{a+t} = x_{b+t}, and the LAST k-mer of the path equals an earlier
+            // one.  A repeat anywhere therefore shows as "the last k-mer was seen before": one thread per fix rolls the path
+            // twice, once to its last k-mer and once comparing (the first form compared every pair behind a 128-bit
+            // filter that long paths saturate, and needed a cooperative path for walks over 48 bases).
             {
-                // short walks (nearly all: a few dozen bases): one thread per fix, its k-mers rebuilt on the fly for every pair
-                bool bad = false, longer = false;
+                bool bad = false;
                 for (uint32_t m = threadIdx.x; m < nb; m += 256) {
                     if (!(e_pos[m] >> 31))
                         continue;
                     const uint32_t cnt = e_uc[m] & 0xffffu;
                     if (cnt > AP_VERIFY) {
                         bad = true;
-                    } else if (cnt > 48u) {
-                        longer = true;
-                    } else {
-                        const uint64_t src = pc_src[e_pi[m]];
-                        const uint32_t *W = a.BW[src >> 60] + (src & 0x0fffffffffffffffull) + (e_ws[m] - e_ws[pc_off[e_pi[m]]]);
-                        const uint32_t w2 = W[2], w3 = cnt > 16u ? W[3] : 0u, w4 = cnt > 32u ? W[4] : 0u;
-                        auto base_at = [&](uint32_t j) { return ((j < 16u ? w2 : (j < 32u ? w3 : w4)) >> (30u - 2u * (j & 15u))) & 3u; };
-                        const uint64_t first_k = ((uint64_t)W[1] << 32) | W[0]; // the k-mer after 0 walked bases
-                        // a 128-bit filter of the k-mers met so far; only a k-mer whose bit is already set is compared with
-                        // the ones before it (rebuilt from the start)
-                        uint64_t ks = first_k, seen0 = 0, seen1 = 0;
-                        for (uint32_t s1 = 0; s1 < cnt; s1++) {
-                            const uint32_t h = (uint32_t)((ks * 0x9E3779B97F4A7C15ull) >> 57);
-                            const uint64_t bitm = 1ull << (h & 63u);
-                            if ((h >> 6 ? seen1 : seen0) & bitm) {
-                                uint64_t kt = first_k;
-                                for (uint32_t t2 = 0; t2 < s1; t2++) {
-                                    bad |= kt == ks;
-                                    kt = ((kt << 2) | base_at(t2 + 1u)) & kmask_;
-                                }
-                            }
-                            if (h >> 6)
-                                seen1 |= bitm;
-                            else
-                                seen0 |= bitm;
-                            if (s1 + 1u < cnt)
-                                ks = ((ks << 2) | base_at(s1 + 1u)) & kmask_;
-                        }
+                        continue;
+                    }
+                    const uint64_t src = pc_src[e_pi[m]];
+                    const uint32_t *W = a.BW[src >> 60] + (src & 0x0fffffffffffffffull) + (e_ws[m] - e_ws[pc_off[e_pi[m]]]);
+                    const uint64_t first_k = ((uint64_t)W[1] << 32) | W[0]; // the k-mer after 0 walked bases (base 0 of the fix is its last)
+                    uint64_t kl = first_k;
+                    uint32_t wcur = W[2];
+                    for (uint32_t j = 1; j < cnt; j++) {
+                        if ((j & 15u) == 0u)
+                            wcur = W[2u + (j >> 4)];
+                        kl = ((kl << 2) | (uint64_t)((wcur >> (30u - 2u * (j & 15u))) & 3u)) & kmask_;
+                    }
+                    uint64_t kt = first_k;
+                    wcur = W[2];
+                    for (uint32_t j = 1; j < cnt; j++) { // kt = the k-mer after j - 1 walked bases
+                        bad |= kt == kl;
+                        if ((j & 15u) == 0u)
+                            wcur = W[2u + (j >> 4)];
+                        kt = ((kt << 2) | (uint64_t)((wcur >> (30u - 2u * (j & 15u))) & 3u)) & kmask_;
                     }
                 }
                 if (__syncthreads_or(bad ? 1 : 0))
                     failed = true;
-                if (!failed && __syncthreads_or(longer ? 1 : 0)) {
-                    records_lost = true;
-                    for (uint32_t m = 0; m < nb && !failed; m++) {
-                        if (!(e_pos[m] >> 31) || (e_uc[m] & 0xffffu) <= 48u)
-                            continue;
-                        const uint32_t cnt = e_uc[m] & 0xffffu;
-                        const uint64_t src = pc_src[e_pi[m]];
-                        const uint32_t *W = a.BW[src >> 60] + (src & 0x0fffffffffffffffull) + (e_ws[m] - e_ws[pc_off[e_pi[m]]]);
-                        const uint32_t nwords = (cnt + 15u) / 16u + 2u;
-                        __syncthreads();
-                        for (uint32_t t = threadIdx.x; t < nwords; t += 256)
-                            vw[t] = W[t];
-                        __syncthreads();
-                        const uint64_t first_k = ((uint64_t)vw[1] << 32) | vw[0];
-                        for (uint32_t sidx = threadIdx.x; sidx < cnt; sidx += 256) {
-                            // the k-mer after sidx walked bases (base 0 of the fix is the last base of first_k itself)
-                            uint64_t km = sidx < (uint32_t)k_ ? first_k : 0ull;
-                            for (uint32_t j = sidx < (uint32_t)k_ ? 1u : sidx - (uint32_t)k_ + 1u; j <= sidx; j++)
-                                km = ((km << 2) | ((vw[2u + (j >> 4)] >> (30u - 2u * (j & 15u))) & 3u)) & kmask_;
-                            vk[sidx] = km;
-                        }
-                        __syncthreads();
-                        int dup = 0;
-                        for (uint32_t sidx = threadIdx.x; sidx < cnt; sidx += 256)
-                            for (uint32_t t2 = sidx + 1u; t2 < cnt; t2++)
-                                dup |= vk[sidx] == vk[t2];
-                        if (__syncthreads_or(dup))
-                            failed = true;
-                    }
-                }
             }
             if (failed)
                 break;
