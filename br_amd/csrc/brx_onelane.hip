@@ -203,6 +203,7 @@ __global__ __launch_bounds__(256) void lane_mask_kernel(LaneArgs a)
     const unsigned long long n_units = p.ctrl[CTL_LANE_UNITS];
     const unsigned long long wave = (unsigned long long)blockIdx.x * 4ull + (threadIdx.x >> 6);
     const unsigned long long n_waves = (unsigned long long)gridDim.x * 4ull;
+    const bool filter = p.idx.line_bits != nullptr && p.idx.line_shift >= 6u; // (line_shift = 32 - log2(lines))
     uint4 ui_next = wave < n_units ? a.u_in[wave] : make_uint4(0, 0, 0, 0);
     uint32_t r_next = wave < n_units ? a.u_read[wave] : 0u;
     for (unsigned long long u = wave; u < n_units; u += n_waves) {
@@ -236,8 +237,10 @@ __global__ __launch_bounds__(256) void lane_mask_kernel(LaneArgs a)
                 if (IDX) {
                     uint64_t key;
                     const uint32_t home = index_locate(p.idx, km, k, key);
-                    // an empty home line answers from its occupancy bit (4 MiB, L2-resident), most k-mers with an error do
-                    if (!p.idx.line_bits || ((p.idx.line_bits[home >> 5] >> (home & 31u)) & 1u)) {
+                    // an empty home line answers from its occupancy bit, and most k-mers with an error point at one -- while
+                    // the bits live in the L2 (4 MiB at 2^25 lines).  Past 2^26 lines every lookup is a request of its own on
+                    // top of the line's (BASELINE configs[4]'s share, 2^28 lines: this kernel 40.1 ms with the bits, 35.1 without)
+                    if (!filter || ((p.idx.line_bits[home >> 5] >> (home & 31u)) & 1u)) {
                         int pr = index_probe_at(p.idx, key, home, 0u);
                         for (uint32_t hop = 1; pr == 2 && !p.bits; hop++)
                             pr = index_probe_at(p.idx, key, home, hop);
