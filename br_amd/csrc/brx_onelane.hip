@@ -1795,6 +1795,9 @@ __global__ __launch_bounds__(256) void lane_apply_walk_kernel(LaneArgs a)
                         __builtin_memcpy(&q, in + e_in[m] + (x0 - e_os[m]), 16);
                         *reinterpret_cast<uint4 *>(ob + x0) = q;
                     } else {
+                        // (the word of written bases in hand is kept from byte to byte: a fix of a walking corrector writes
+                        // several bases, and a load per byte was most of what this kernel cost beyond One's)
+                        uint32_t w = 0, w_m = 0xffffffffu, w_i = 0;
                         for (uint32_t x = x0; x < x1; x++) {
                             while (x >= e_os[m + 1])
                                 m++;
@@ -1803,9 +1806,13 @@ __global__ __launch_bounds__(256) void lane_apply_walk_kernel(LaneArgs a)
                                 ob[x] = in[e_in[m] + rel];
                             } else {
                                 const uint32_t tb = rel - seglen; // base tb of the fix
-                                const uint64_t src = pc_src[e_pi[m]];
-                                const uint32_t first_fix = pc_off[e_pi[m]];
-                                const uint32_t w = a.BW[src >> 60][(src & 0x0fffffffffffffffull) + (e_ws[m] - e_ws[first_fix]) + ((e_pos[m] >> 31) ? 2u : 0u) + (tb >> 4)];
+                                if (w_m != m || w_i != (tb >> 4)) {
+                                    const uint64_t src = pc_src[e_pi[m]];
+                                    const uint32_t first_fix = pc_off[e_pi[m]];
+                                    w_m = m;
+                                    w_i = tb >> 4;
+                                    w = a.BW[src >> 60][(src & 0x0fffffffffffffffull) + (e_ws[m] - e_ws[first_fix]) + ((e_pos[m] >> 31) ? 2u : 0u) + w_i];
+                                }
                                 ob[x] = bit2nuc((w >> (30u - 2u * (tb & 15u))) & 3u);
                             }
                         }
