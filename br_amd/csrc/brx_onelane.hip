@@ -263,60 +263,76 @@ __global__ __launch_bounds__(256) void lane_mask_kernel(LaneArgs a)
     }
 }
 
-// One wave per unit boundary: the first position q > j*C + k behind R solid original k-mers in a row, inside the unit's
+// Half a wave per unit boundary: the first position q > j*C + k behind R solid original k-mers in a row, inside the unit's
 // own nominal stretch; none -> the unit is void.  q is the loop-top position (mod.rs:68), u_qk the k-mer in front of it.
+// 32 positions per step and unit, every one of them a k-mer that lies inside the stretch (they are cut from the packed
+// copy, three dwords each, so no lane is spent on the k - 1 bases in front of the first one): a run of four turns up
+// within the first 32 nearly always, and the first form -- a wave per unit, 64 positions per step of which the first
+// k - 1 could not count -- made twice the probes (1.4 -> 0.9 ms at configs[1]).
 template <bool IDX>
 __global__ __launch_bounds__(256) void lane_sync_kernel(LaneArgs a)
 {
     const PassParams &p = a.p;
-    const int lane = threadIdx.x & 63;
-    const int k = p.k;
-    const uint64_t mask = kmask(k);
+    const uint32_t lane = threadIdx.x & 63u, half = lane >> 5, hl = lane & 31u;
+    const uint32_t k = (uint32_t)p.k;
     const unsigned long long n_units = p.ctrl[CTL_LANE_UNITS];
     const unsigned long long wave = (unsigned long long)blockIdx.x * 4ull + (threadIdx.x >> 6);
     const unsigned long long n_waves = (unsigned long long)gridDim.x * 4ull;
-    uint4 ui_next = wave < n_units ? a.u_in[wave] : make_uint4(0, 0, 0, 0);
-    for (unsigned long long u = wave; u < n_units; u += n_waves) {
-        const uint4 ui = ui_next; // (one load instead of unit -> read -> offsets / lengths / unit base; loaded an iteration ahead)
-        if (u + n_waves < n_units)
-            ui_next = a.u_in[u + n_waves];
+    for (unsigned long long u0 = 2ull * wave; u0 < n_units; u0 += 2ull * n_waves) {
+        const unsigned long long u = u0 + half;
+        const bool mine = u < n_units;
+        const uint4 ui = mine ? a.u_in[u] : make_uint4(0, 0, 0, 0);
         const uint32_t j = ui.w, n = ui.z;
-        if (j == 0) {
-            if (lane == 0)
-                a.u_q[u] = 0;
-            continue;
-        }
-        const uint8_t *in = p.in + (((uint64_t)ui.y << 32) | ui.x);
+        const uint32_t r = mine ? a.u_read[u] : 0u;
+        const uint64_t at = ((uint64_t)ui.y << 32) | ui.x;
+        const uint32_t *row = a.P + pack_start(at, r);
         const uint32_t s = j * a.C;
-        const uint32_t lim = (s + a.C < n) ? s + a.C : n; // k-mers ending at e < lim
-        uint32_t q = U_VOID;
-        uint64_t qk = 0, carry = 0, prev_ball = 0;
-        for (uint32_t t = 0; s + 64u * t < lim; t++) {
-            const uint32_t e = s + 64u * t + (uint32_t)lane;
-            const uint32_t code = e < n ? (uint32_t)nuc2bit(in[e]) : 0u;
-            const uint64_t km = lane_kmer64_dpp(carry, code, lane, mask);
-            const bool valid = e < lim && e + 1u >= s + (uint32_t)k; // the k-mer lies inside [s, lim)
-            const bool sol = valid && set_get<IDX>(p, km, k);
+        const uint32_t lim = (s + a.C < n) ? s + a.C : n; // k-mers ending at e < lim ...
+        const uint32_t e0 = s + k - 1u;                    // ... and starting at or behind s
+        bool open_ = mine && j != 0u;                     // this half still looks for its unit's sync point
+        uint32_t q = (mine && j == 0u) ? 0u : U_VOID;
+        uint64_t qk = 0;
+        uint32_t prev32 = 0;
+        for (uint32_t t = 0; __any(open_ && e0 + 32u * t < lim); t++) {
+            const uint32_t e = e0 + 32u * t + hl;
+            const bool valid = open_ && e < lim;
+            uint64_t km = 0;
+            bool sol = false;
+            if (valid) {
+                const uint32_t b = e + 1u - k, wd = b >> 4, sh = 2u * (b & 15u);
+                const uint64_t hi = ((uint64_t)row[wd] << 32) | row[wd + 1];
+                const uint64_t lo = row[wd + 2];
+                km = (sh ? ((hi << sh) | (lo >> (32u - sh))) : hi) >> (64u - 2u * k);
+                sol = set_get<IDX>(p, km, (int)k);
+            }
             const uint64_t ball = __ballot(sol);
-            uint64_t x = ball;
+            const uint32_t cur32 = (uint32_t)(ball >> (32u * half));
+            const uint64_t w = ((uint64_t)cur32 << 32) | prev32; // the half's last 64 answers, this step's in the top half
+            uint64_t x = w;
             for (uint32_t rr = 1; rr < a.R; rr++)
-                x &= (ball << rr) | (prev_ball >> (64u - rr));
-            if (x) {
-                const int el = __builtin_ctzll(x);
-                const uint32_t qq = s + 64u * t + (uint32_t)el + 1u;
+                x &= w << rr;
+            const uint32_t hit = (uint32_t)(x >> 32);
+            const bool found = open_ && hit != 0u;
+            const uint32_t el_l = found ? (uint32_t)__builtin_ctz(hit) : 0u; // lane of the half whose k-mer ends the run
+            // (every lane takes part in the shuffles; the source lane is in the asker's own half)
+            const uint32_t src = 32u * half + el_l;
+            const uint32_t klo = (uint32_t)__shfl((int)(uint32_t)km, (int)src), khi = (uint32_t)__shfl((int)(uint32_t)(km >> 32), (int)src);
+            if (found) {
+                const uint32_t qq = e0 + 32u * t + el_l + 1u;
                 if (qq < n) {
                     q = qq;
-                    qk = ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(km >> 32), el) << 32) | (uint32_t)__shfl((int)(uint32_t)km, el);
+                    qk = ((uint64_t)khi << 32) | klo;
                 }
-                break;
+                open_ = false;
+            } else if (open_ && e0 + 32u * (t + 1u) >= lim) {
+                open_ = false;
             }
-            prev_ball = ball;
-            carry = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(km >> 32), 63) << 32) |
-                    (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)km, 63);
+            prev32 = cur32;
         }
-        if (lane == 0) {
+        if (mine && hl == 0u) {
             a.u_q[u] = q;
-            a.u_qk[u] = qk;
+            if (j != 0u)
+                a.u_qk[u] = qk;
         }
     }
 }
