@@ -335,7 +335,17 @@ def main():
             host = host_8192(args, d_bases, d_off, n_reads, gs)
             e2e = e2e_fasta(args, d_bases, d_off, n_reads, total, k, a)
         if not args.no_cpu_baseline:
-            cpu = cpu_baseline(args, cfg, gs, k, n_reads)
+            cpu = cpu_baseline(args, cfg, gs, k, n_reads, d_out, d_out_off)
+            if cpu and "parity" in cpu:
+                # the CPU leg corrects its sample anyway: every read of it is compared with what the timed GPU step wrote
+                checks["parity_reads"] = cpu["parity"]["reads_compared"]
+                checks["parity_mismatches"] = cpu["parity"]["mismatches"]
+                if cpu["parity"]["reads_compared"] == n_reads:
+                    checks["parity_fixes_equal"] = bool(int(stats["fixes"]) == cpu["parity"]["oracle_fixes"])
+                if cpu["parity"]["mismatches"]:
+                    print("bench.py: %d of %d reads differ from the oracle (first: read %s)" %
+                          (cpu["parity"]["mismatches"], cpu["parity"]["reads_compared"], cpu["parity"]["first_mismatching_read"]),
+                          file=sys.stderr)
 
     if rank == 0:
         value = total_all * args.steps / elapsed / 1e9
@@ -410,7 +420,7 @@ def usable_cpus():
     return n, how
 
 
-def cpu_baseline(args, cfg, gs, k, n_reads):
+def cpu_baseline(args, cfg, gs, k, n_reads, d_out=None, d_out_off=None):
     """Times the CPU oracle (restatement of the reference's path; the Rust reference itself cannot be built
     offline) on a bounded sample of the same workload, with pthread workers on every core of the box
     (oracle/br_oracle.c: bro_correct_batch_mt / bro_count_batch_mt, the shape of the reference's rayon path):
@@ -443,14 +453,25 @@ def cpu_baseline(args, cfg, gs, k, n_reads):
         keep = np.ascontiguousarray(hs[gs.get_many(canon)], dtype=np.uint64)
         solid = O.Solid(k, _h=O.lib().bro_solid_new_sparse(k, keep.ctypes.data, keep.size))
         set_desc = "the GPU-built sparse k=%d set restricted to the sample's k-mers" % k
+    # what the GPU wrote for the same reads in the last timed step (the oracle here is the checker of that output, never
+    # a source of it): compared read by read inside the workers, after each read's correction
+    expect = expect_off = None
+    if d_out is not None and d_out_off is not None:
+        expect_off = d_out_off[:S + 1].cpu().numpy().astype(np.uint64)
+        expect = d_out[:int(expect_off[-1])].cpu().numpy()
     t0 = time.perf_counter()
-    _, out_bytes, fixes = O.correct_batch_mt(solid, args.methods, bases, offs, args.confirm, 7, False, cores)
+    _, out_bytes, fixes, n_bad, first_bad = O.correct_batch_mt_check(solid, args.methods, bases, offs, expect, expect_off,
+                                                                      args.confirm, 7, False, cores)
     dt = time.perf_counter() - t0
     nb = int(offs[S])
     res = {"value": round(nb / dt / 1e9, 5), "unit": "Gbases/s", "cores": cores, "nproc": os.cpu_count(),
            "cores_how": how, "kind": "port",
            "sample": "%s fwd+rev of the first %d reads (%.1f Mbp) against %s; correction phase only, %d pthreads "
                      "pulling 16-record blocks, %.1f s, %d fixes" % (" + ".join(args.methods), S, nb / 1e6, set_desc, cores, dt, fixes)}
+    if expect_off is not None:
+        res["parity"] = {"reads_compared": S, "mismatches": n_bad, "first_mismatching_read": first_bad,
+                         "oracle_fixes": fixes, "oracle_out_bases": out_bytes, "gpu_out_bases": int(expect_off[-1]),
+                         "what": "every read of the sample: bytes of the timed GPU step's output vs the oracle's"}
     # set-build leg
     kb = min(k, 17)
     Sb = int(min(S, 1600 * cores))     # ~0.1 ms per 10 kb read on one thread (DRAM-latency-bound RMW): a few seconds, so that

@@ -73,7 +73,7 @@ class Chain:
         _lib.check(_lib.lib().brx_chain_last_stats(self._h, a))
         return {"rounds": a[0], "probes": a[1], "triggers": a[2], "fixes": a[3], "overflow_retries": a[4],
                 "slot_overflow_reads": a[5], "walk_list_overflows": a[6], "lane_units": a[7] & 0xffffffff,
-                "lane_redone_reads": a[7] >> 32}
+                "lane_redone_reads": (a[7] >> 32) & 0xffffff, "lane_unwritten_units": a[7] >> 56}
 
 
 class Corrector:

@@ -2437,7 +2437,13 @@ static int correct_batch_device_locked(brx_chain_t *ch, const uint8_t *d_bases, 
                 continue;
             }
         }
-        stats[7] = (ch->h_ctrl[CTL_LANE_UNITS] & 0xffffffffull) | (ch->h_ctrl[CTL_LANE_FAIL] << 32);
+        {
+            const uint64_t unw = ch->h_ctrl[CTL_LANE_UNWRITTEN] + (ch->sub ? ch->sub->last_stats[7] >> 56 : 0);
+            stats[7] = (ch->h_ctrl[CTL_LANE_UNITS] & 0xffffffffull) | ((ch->h_ctrl[CTL_LANE_FAIL] & 0xffffffull) << 32) |
+                       ((unw > 255 ? 255ull : unw) << 56);
+            if (unw) // an invariant of the lane form is broken (the output is still right: those reads went to the group kernel)
+                fprintf(stderr, "[brx correct] WARNING: %llu unit record(s) were never written by the lane pass\n", (unsigned long long)unw);
+        }
         stats[0] += ch->h_ctrl[CTL_ROUNDS];
         stats[1] += ch->h_ctrl[CTL_PROBES];
         stats[2] += ch->h_ctrl[CTL_TRIGGERS];

@@ -11,6 +11,10 @@ enum { CTL_WORK = 0, CTL_OVERFLOW = 1, CTL_ROUNDS = 2, CTL_PROBES = 3, CTL_TRIGG
        // the lane-per-chunk form of One's forward pass (brx_onelane.hip): units of the pass, predictions that missed,
        // its work counter, reads handed back to the group kernel
        CTL_LANE_UNITS = 9, CTL_LANE_MISS = 10, CTL_LANE_WORK = 11, CTL_LANE_FAIL = 12,
+       // (not reset per pass: summed over the attempt) unit records the replay kernel found UNWRITTEN -- every unit is
+       // taken by exactly one lane and leaves a record, so this stays 0; the records are filled with ones before the
+       // automaton runs so that a unit nobody scanned could not pass for a result (its read goes to the group kernel)
+       CTL_LANE_UNWRITTEN = 15,
        CTL_N = 16 };
 
 struct PassParams {

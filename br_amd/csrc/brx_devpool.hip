@@ -32,6 +32,28 @@ std::vector<Parked> g_parked;
 size_t g_parked_bytes = 0;
 constexpr size_t POOL_MIN = 32ull << 20;
 
+// BRX_DEBUG_POISON=1 (read once): every block handed out -- fresh from the runtime or recycled from the pool -- is filled
+// with 0xA5 first, so that a kernel that reads memory nobody wrote in ITS job meets the same garbage on every run and on
+// every box instead of whatever the block's last user left (tools/fuzz_parity.py and the GPU suite are run under it).
+bool poison_on()
+{
+    static const bool on = [] {
+        const char *e = getenv("BRX_DEBUG_POISON");
+        return e && *e && *e != '0';
+    }();
+    return on;
+}
+
+hipError_t poison(void *p, size_t bytes)
+{
+    if (!poison_on())
+        return hipSuccess;
+    hipError_t e = hipMemset(p, 0xA5, bytes);
+    if (e == hipSuccess)
+        e = hipDeviceSynchronize(); // (hipMemset on device memory does not wait; streams here are non-blocking)
+    return e;
+}
+
 size_t pool_cap()
 {
     static const size_t cap = [] {
@@ -71,9 +93,10 @@ hipError_t dev_alloc(void **out, size_t bytes)
             g_parked_bytes -= b.bytes;
             g_live[b.p] = b.bytes;
             *out = b.p;
-            return hipSuccess;
         }
     }
+    if (*out)
+        return poison(*out, bytes);
     hipError_t e = hipMalloc(out, bytes);
     if (e == hipErrorOutOfMemory) {
         (void)hipGetLastError();
@@ -90,6 +113,8 @@ hipError_t dev_alloc(void **out, size_t bytes)
         std::lock_guard<std::mutex> g(g_mu);
         g_live[*out] = bytes;
     }
+    if (e == hipSuccess)
+        e = poison(*out, bytes);
     return e;
 }
 
@@ -108,17 +133,23 @@ hipError_t dev_free(void *p)
     }
     if (bytes == 0 || pool_cap() == 0)
         return hipFree(p); // small, or not one of the pool's
-    // what hipFree would have waited for: kernels that still use the block
-    const hipError_t se = hipDeviceSynchronize();
-    if (se != hipSuccess)
-        return hipFree(p);
-    int dev = 0;
-    (void)hipGetDevice(&dev);
+    // what hipFree would have waited for: kernels that still use the block -- on the device the BLOCK lives on, which
+    // need not be the calling thread's current one (brx_comm_init_all's per-device threads)
+    int cur = 0, dev = 0;
+    (void)hipGetDevice(&cur);
+    dev = cur;
     hipPointerAttribute_t at;
     if (hipPointerGetAttributes(&at, p) == hipSuccess)
         dev = at.device;
     else
         (void)hipGetLastError();
+    if (dev != cur)
+        (void)hipSetDevice(dev);
+    const hipError_t se = hipDeviceSynchronize();
+    if (dev != cur)
+        (void)hipSetDevice(cur);
+    if (se != hipSuccess)
+        return hipFree(p);
     std::vector<void *> drop;
     {
         std::lock_guard<std::mutex> g(g_mu);

@@ -34,6 +34,7 @@ struct Rccl {
     ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr; // optional
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
     ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
@@ -79,6 +80,7 @@ int rccl_load()
     SYM(AllReduce, "ncclAllReduce")
     SYM(GetErrorString, "ncclGetErrorString")
 #undef SYM
+    *(void **)(&r.CommAbort) = dlsym(h, "ncclCommAbort"); // (not required: without it a failed rank can only leave)
     g_rccl = r;
     return BRX_OK;
 }
@@ -141,6 +143,11 @@ struct brx_comm {
     uint64_t zero_tab_cap = 0;
     uint64_t stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     uint64_t rounds_a2a = 0, rounds_gather = 0;
+    // how the current call failed, if it did: a failure every rank KNOWS about (it went through a status exchange) lets
+    // all of them return together; one that only this rank saw -- a HIP call or a collective that failed between two
+    // exchanges -- would leave the peers waiting in their next collective for ever, so the communicator is aborted
+    // (ncclCommAbort: the peers' pending and later collectives return an error) and is dead from then on
+    bool agreed_failure = false, dead = false;
     std::mutex mu;
 };
 
@@ -218,8 +225,10 @@ int all_to_all_v(brx_comm *cm, const uint32_t *send, const uint64_t *send_counts
 int agree(brx_comm *cm, int local, hipStream_t s)
 {
     const int W = cm->world, me = cm->rank;
-    if (W == 1)
+    if (W == 1) {
+        cm->agreed_failure = local != BRX_OK;
         return local;
+    }
     const uint64_t mine = (uint64_t)(int64_t)local;
     std::vector<uint64_t> all(W, 0);
     hipError_t e = hipMemcpy(cm->d_counts + me, &mine, 8, hipMemcpyHostToDevice);
@@ -237,11 +246,14 @@ int agree(brx_comm *cm, int local, hipStream_t s)
         set_error("exchange: status exchange: %s", hipGetErrorString(e));
         return local != BRX_OK ? local : BRX_ERR_HIP;
     }
-    if (local != BRX_OK)
+    if (local != BRX_OK) {
+        cm->agreed_failure = true; // (every peer has read this rank's status and returns too)
         return local; // (its message is already set)
+    }
     for (int r = 0; r < W; r++)
         if ((int64_t)all[r] != BRX_OK) {
             set_error("exchange: rank %d failed (%s); rank %d leaves the exchange with it", r, brx_strerror((int)(int64_t)all[r]), me);
+            cm->agreed_failure = true;
             return (int)(int64_t)all[r];
         }
     return BRX_OK;
@@ -447,6 +459,18 @@ int gather_lists(brx_comm *cm, const std::vector<uint64_t> &n_of, const std::vec
     return BRX_OK;
 }
 
+// a failure only this rank saw: the peers must not be left in their next collective (see brx_comm::agreed_failure)
+void abort_after_local_failure(brx_comm *cm)
+{
+    if (cm->world == 1 || cm->agreed_failure || cm->dead)
+        return;
+    cm->dead = true;
+    if (cm->comm && g_rccl.CommAbort) {
+        (void)g_rccl.CommAbort(cm->comm); // (frees the communicator)
+        cm->comm = nullptr;
+    }
+}
+
 struct ExchangeJob {
     uint64_t *d_extracted = nullptr; // owned: freed by the caller whatever happens
     bool counter_borrows = false;    // the counter refers to cm->d_recv: reset it before returning
@@ -546,12 +570,15 @@ int exchange_body(brx_comm *cm, brx_counter_t *c, uint8_t abundance, brx_set_t *
     BRX_NCCL(g_rccl.AllGather(cm->d_counts + 2 * me, cm->d_counts, 2, ncclUint64, cm->comm, s)); // in place
     BRX_HIP(hipMemcpyAsync(got.data(), cm->d_counts, (size_t)W * 16, hipMemcpyDeviceToHost, s));
     BRX_HIP(hipStreamSynchronize(s));
-    if (local != BRX_OK)
+    if (local != BRX_OK) {
+        cm->agreed_failure = true; // (the size exchange carried it to everybody)
         return local;
+    }
     std::vector<uint64_t> n_of(W), off(W + 1, 0);
     for (int r = 0; r < W; r++) {
         if ((int64_t)got[2 * r + 1] != BRX_OK) {
             set_error("exchange: rank %d failed to finish its digit range (%s)", r, brx_strerror((int)(int64_t)got[2 * r + 1]));
+            cm->agreed_failure = true;
             return (int)(int64_t)got[2 * r + 1];
         }
         n_of[r] = got[2 * r];
@@ -606,11 +633,18 @@ int brx_exchange_build_partitioned(brx_comm_t *cm, brx_counter_t *c, uint8_t abu
     }
     BRX_TRY(use_device(cm->device));
     std::lock_guard<std::mutex> g(cm->mu);
+    if (cm->dead) {
+        set_error("exchange: this communicator was aborted after a failure on this rank; make a new one");
+        return BRX_ERR_UNSUPPORTED;
+    }
+    cm->agreed_failure = false;
     hipStream_t s = (hipStream_t)stream;
     if (local != BRX_OK)
         return agree(cm, local, s);
     ExchangeJob job;
     const int rc = exchange_body(cm, c, abundance, dst, s, job);
+    if (rc != BRX_OK)
+        abort_after_local_failure(cm);
     // ONE way out: whatever happened, the counter is empty again and no longer refers to the receive buffer
     if (job.d_extracted)
         (void)hipFree(job.d_extracted);
@@ -623,13 +657,27 @@ int brx_exchange_build_partitioned(brx_comm_t *cm, brx_counter_t *c, uint8_t abu
     return rst;
 }
 
+static int reduce_counts_body(brx_comm_t *cm, brx_counter_t *c, uint8_t abundance, hipStream_t s);
+
 int brx_exchange_reduce_counts(brx_comm_t *cm, brx_counter_t *c, uint8_t abundance, void *stream)
 {
     if (!cm || !c)
         return BRX_ERR_ARG;
     BRX_TRY(use_device(cm->device));
     std::lock_guard<std::mutex> g(cm->mu);
-    hipStream_t s = (hipStream_t)stream;
+    if (cm->dead) {
+        set_error("exchange: this communicator was aborted after a failure on this rank; make a new one");
+        return BRX_ERR_UNSUPPORTED;
+    }
+    cm->agreed_failure = false;
+    const int rc = reduce_counts_body(cm, c, abundance, (hipStream_t)stream);
+    if (rc != BRX_OK)
+        abort_after_local_failure(cm);
+    return rc;
+}
+
+static int reduce_counts_body(brx_comm_t *cm, brx_counter_t *c, uint8_t abundance, hipStream_t s)
+{
     void *d_counts = nullptr;
     uint64_t nbytes = 0;
     int local = BRX_OK;

@@ -52,6 +52,7 @@ constexpr uint32_t U_VOID = 0xffffffffu;   // u_q: the unit found no sync point 
 constexpr uint32_t U_END = 0xffffffffu;    // a target: the end of the read
 constexpr uint32_t C_FAIL = 0xfffffff1u;   // res[6]: three misses in a row, or an edit list overflowed: back to the group kernel
 constexpr uint32_t C_VOID = 0xfffffff2u;   // res[6]: nothing produced
+constexpr uint32_t U_UNWRITTEN = 0xffffffffu; // res[6] as lane_pass leaves it before the automaton: no lane has been here
 constexpr int MAX_DEPTH = 3;               // edit lists: own stretch + two stretches scanned after a miss
 constexpr uint32_t MAX_LANE_READ = 1u << 28; // positions are kept in 28 bits of an edit
 constexpr uint32_t AP_EDITS = 512;  // fixes replayed per batch
@@ -486,12 +487,14 @@ __global__ __launch_bounds__(256, MASK ? 6 : BRX_LANE_WAVES) void lane_kernel(La
     // the scan (mod.rs:60-67) and the trigger in progress
     uint64_t kmer = 0, corr = 0;
     uint32_t S = 0, hop = 0, cline = 0xffffffffu;
-    uint32_t n_rounds = 0, n_probes = 0, n_trig = 0, n_fix = 0, n_miss = 0; // wave-uniform (scalar registers)
+    // (fixes are not counted here: a unit that started on a wrong prediction, or a stretch scanned a second time after
+    // a miss, makes fixes nobody keeps -- the replay kernel counts the ones it commits)
+    uint32_t n_rounds = 0, n_probes = 0, n_trig = 0, n_miss = 0; // wave-uniform (scalar registers)
     uint32_t wnext = 0, wend = 0; // the units this wave has drawn and not yet dealt out (wave-uniform)
 
     for (;;) {
         // ---- rare: a unit ends where the scan reaches its target (loop top, mod.rs:68); units are handed out --------
-        uint32_t ev = 0; // this lane's events of the round: 1 probe, 2 trigger, 4 fix, 8 missed prediction
+        uint32_t ev = 0; // this lane's events of the round: 1 probe, 2 trigger, 8 missed prediction, 16 a second probe
         const bool at_end = have && (S & 3u) == 0u && i >= tgt;
         if (__any(at_end || want)) {
             if (at_end) {
@@ -782,7 +785,7 @@ __global__ __launch_bounds__(256, MASK ? 6 : BRX_LANE_WAVES) void lane_kernel(La
                 const uint64_t krun = ((kmer << (2u * run)) | (wreg >> (64u - 2u * run))) & mask; // (run >= 1)
                 kmer = accept ? (clean ? krun : (acceptB ? pk2 : pk)) : (fail ? ((corr & ~3ull) | (uint64_t)c0) : (fix ? kfix : kmer));
                 corr = trigA ? pk : (trigB ? pk2 : (to_scen ? ((corr & ~3ull) | (uint64_t)win) : corr));
-                ev |= (trig ? 2u : 0u) | (fix ? 4u : 0u);
+                ev |= trig ? 2u : 0u;
                 if (apply_b) { // mod.rs:75-89: one base out, `used` bases of the read consumed -- the lane's only output
                     if (room) {
                         a.E[depth][eat + ne] = (i << 4) | (used << 2) | (uint32_t)(corr & 3ull);
@@ -802,7 +805,6 @@ __global__ __launch_bounds__(256, MASK ? 6 : BRX_LANE_WAVES) void lane_kernel(La
         // every lane back together: count the round's events
         n_probes += (uint32_t)__builtin_popcountll(__ballot(ev & 1u)) + (uint32_t)__builtin_popcountll(__ballot(ev & 16u));
         n_trig += (uint32_t)__builtin_popcountll(__ballot(ev & 2u));
-        n_fix += (uint32_t)__builtin_popcountll(__ballot(ev & 4u));
         n_miss += (uint32_t)__builtin_popcountll(__ballot(ev & 8u));
     }
     // statistics: one atomic per wave per counter
@@ -813,8 +815,6 @@ __global__ __launch_bounds__(256, MASK ? 6 : BRX_LANE_WAVES) void lane_kernel(La
             atomicAdd(p.ctrl + CTL_PROBES, (unsigned long long)n_probes);
         if (n_trig)
             atomicAdd(p.ctrl + CTL_TRIGGERS, (unsigned long long)n_trig);
-        if (n_fix)
-            atomicAdd(p.ctrl + CTL_FIXES, (unsigned long long)n_fix);
         if (n_miss)
             atomicAdd(p.ctrl + CTL_LANE_MISS, (unsigned long long)n_miss);
     }
@@ -932,7 +932,7 @@ __global__ __launch_bounds__(256, walk_waves(M)) void lane_walk_kernel(LaneArgs 
     uint32_t S = 0, hop = 0, cline = 0xffffffffu;
     uint64_t csucc = 0; // the successor bytes of the line held in LDS
     uint32_t elen = 0, bpow = 1, blam = 0, np = 0, pacc = 0;
-    uint32_t n_rounds = 0, n_probes = 0, n_trig = 0, n_fix = 0, n_miss = 0;
+    uint32_t n_rounds = 0, n_probes = 0, n_trig = 0, n_miss = 0; // (fixes: counted by the replay kernel, as for One)
     uint32_t wnext = 0, wend = 0;
 
     for (;;) {
@@ -1250,7 +1250,6 @@ __global__ __launch_bounds__(256, walk_waves(M)) void lane_walk_kernel(LaneArgs 
                     }
                     a.EW[depth][(eat >> 1) + ne] = make_uint2(i | ((fix_walk && mode == (uint32_t)WM_INSSUB) ? 0x80000000u : 0u), (usd << 16) | cnt);
                     ne++;
-                    ev |= 4u;
                 }
                 if (fail && (is_walk || is_wfast))
                     bw = bw0; // a failed walk leaves no bases behind
@@ -1356,7 +1355,6 @@ __global__ __launch_bounds__(256, walk_waves(M)) void lane_walk_kernel(LaneArgs 
         }
         n_probes += (uint32_t)__builtin_popcountll(__ballot(ev & 1u));
         n_trig += (uint32_t)__builtin_popcountll(__ballot(ev & 2u));
-        n_fix += (uint32_t)__builtin_popcountll(__ballot(ev & 4u));
         n_miss += (uint32_t)__builtin_popcountll(__ballot(ev & 8u));
     }
     if ((threadIdx.x & 63) == 0) {
@@ -1366,8 +1364,6 @@ __global__ __launch_bounds__(256, walk_waves(M)) void lane_walk_kernel(LaneArgs 
             atomicAdd(p.ctrl + CTL_PROBES, (unsigned long long)n_probes);
         if (n_trig)
             atomicAdd(p.ctrl + CTL_TRIGGERS, (unsigned long long)n_trig);
-        if (n_fix)
-            atomicAdd(p.ctrl + CTL_FIXES, (unsigned long long)n_fix);
         if (n_miss)
             atomicAdd(p.ctrl + CTL_LANE_MISS, (unsigned long long)n_miss);
     }
@@ -1413,6 +1409,7 @@ __global__ __launch_bounds__(AP_BS) void lane_apply_kernel(LaneArgs a)
         uint32_t cur_in = 0; // input bases consumed so far (uniform)
         bool failed = false, more = true;
         uint32_t u_next = ub, d_next = 0; // where the chain walk goes on (uniform)
+        uint32_t committed = 0;           // fixes replayed so far (uniform)
         __syncthreads();
         if (ub + threadIdx.x < (uint32_t)a.ubase[r + 1]) {
             const uint32_t uu = ub + threadIdx.x;
@@ -1434,6 +1431,8 @@ __global__ __launch_bounds__(AP_BS) void lane_apply_kernel(LaneArgs a)
                     const uint32_t res[8] = {ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z, rb.w};
                     const uint32_t code = res[6];
                     if (code >= (uint32_t)MAX_DEPTH) { // FAIL, or a void unit on the chain (cannot be)
+                        if (code == U_UNWRITTEN)
+                            atomicAdd(p.ctrl + CTL_LANE_UNWRITTEN, 1ull);
                         state = 2;
                         break;
                     }
@@ -1561,6 +1560,7 @@ __global__ __launch_bounds__(AP_BS) void lane_apply_kernel(LaneArgs a)
                     }
                 }
                 total += batch_total;
+                committed += nb;
                 cur_in = (e_raw[nb - 1] >> 4) + ((e_raw[nb - 1] >> 2) & 3u);
             }
         }
@@ -1580,6 +1580,10 @@ __global__ __launch_bounds__(AP_BS) void lane_apply_kernel(LaneArgs a)
                 atomicAdd(p.ctrl + CTL_OVERFLOW, 1ull);
             } else {
                 p.out_lens[r] = (uint32_t)total;
+                // the fixes of the pass (brx_chain_last_stats): the ones written into a read that is kept.  A read handed
+                // back to the group kernel is counted there, one redone with more slack by the chain that redoes it.
+                if (committed)
+                    atomicAdd(p.ctrl + CTL_FIXES, (unsigned long long)committed);
             }
         }
     }
@@ -1623,6 +1627,7 @@ __global__ __launch_bounds__(256) void lane_apply_walk_kernel(LaneArgs a)
         uint32_t cur_in = 0;
         bool failed = false, more = true;
         uint32_t u_next = ub, d_next = 0;
+        uint32_t committed = 0; // fixes replayed so far (uniform)
         __syncthreads();
         if (ub + threadIdx.x < (uint32_t)a.ubase[r + 1]) {
             const uint32_t uu = ub + threadIdx.x;
@@ -1643,6 +1648,8 @@ __global__ __launch_bounds__(256) void lane_apply_walk_kernel(LaneArgs a)
                     const uint32_t res[8] = {ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z, rb.w};
                     const uint32_t code = res[6];
                     if (code >= (uint32_t)MAX_DEPTH) {
+                        if (code == U_UNWRITTEN)
+                            atomicAdd(p.ctrl + CTL_LANE_UNWRITTEN, 1ull);
                         state = 2;
                         break;
                     }
@@ -1836,6 +1843,7 @@ __global__ __launch_bounds__(256) void lane_apply_walk_kernel(LaneArgs a)
                 }
             }
             total += batch_total;
+            committed += nb;
             cur_in = (e_pos[nb - 1] & 0x7fffffffu) + (e_uc[nb - 1] >> 16);
         }
         if (!failed && n > cur_in) {
@@ -1853,6 +1861,8 @@ __global__ __launch_bounds__(256) void lane_apply_walk_kernel(LaneArgs a)
                 atomicAdd(p.ctrl + CTL_OVERFLOW, 1ull);
             } else {
                 p.out_lens[r] = (uint32_t)total;
+                if (committed)
+                    atomicAdd(p.ctrl + CTL_FIXES, (unsigned long long)committed);
             }
         }
     }
@@ -2070,6 +2080,10 @@ int lane_pass(brx_chain *ch, const PassParams &p, const LanePassInfo &info, hipS
             const uint64_t blocks = (n_lines + 255ull) / 256ull;
             succ_build_kernel<<<(uint32_t)(blocks < 65536ull ? blocks : 65536ull), 256, 0, s>>>(p, n_lines, set->d_succ);
             BRX_HIP(hipGetLastError());
+            // the table belongs to the SET: another chain on it (its own stream, another host thread) takes the generation
+            // below as "built" the moment the lock is released, so the kernel has to be through by then (the index build
+            // does the same, brx_index.hip)
+            BRX_HIP(hipStreamSynchronize(s));
             set->succ_gen = set->idx_gen;
         }
         a.succ = set->d_succ;
@@ -2078,7 +2092,10 @@ int lane_pass(brx_chain *ch, const PassParams &p, const LanePassInfo &info, hipS
     const uint32_t rb = (p.n_reads + 255u) / 256u;
     {
         KernelTimer t("lane_units", s);
-        BRX_HIP(hipMemsetAsync(p.ctrl + CTL_LANE_UNITS, 0, (CTL_N - CTL_LANE_UNITS) * 8, s));
+        BRX_HIP(hipMemsetAsync(p.ctrl + CTL_LANE_UNITS, 0, (CTL_LANE_FAIL + 1 - CTL_LANE_UNITS) * 8, s));
+        // every unit's record starts as "unwritten" (all ones): lane_apply hands a read with such a record to the group
+        // kernel and counts it, instead of replaying whatever the memory held (32 B per unit: microseconds)
+        BRX_HIP(hipMemsetAsync(w->u_res, 0xff, units_bound * 32ull, s));
         lane_units_kernel<<<rb, 256, 0, s>>>(a);
         BRX_TRY(exclusive_scan_lens(w->nu, p.n_reads, ch->d_scan_tmp, w->ubase, p.ctrl + CTL_LANE_UNITS, s));
         const uint32_t grid = p.n_reads < (1u << 16) ? p.n_reads : (1u << 16);

@@ -244,11 +244,14 @@ int brx_chain_correct_batch(brx_chain_t *chain, const uint8_t *bases, const uint
 int brx_chain_correct_batch_device(brx_chain_t *chain, const uint8_t *d_bases, const uint64_t *d_offsets,
                                    uint32_t n_reads, uint64_t total_bases, uint8_t *d_out, uint64_t out_cap,
                                    uint64_t *d_out_offsets, uint64_t *out_total, void *stream);
-/* counters of the last batch: [0] scan rounds, [1] probes issued, [2] triggers, [3] fixes,
+/* counters of the last batch: [0] scan rounds, [1] probes issued, [2] triggers, [3] fixes -- the fixes WRITTEN into the
+ * reads that came back (Some(..) returns of correct_error, src/correct/mod.rs:75: the oracle's count), whereas
+ * [0]-[2] count work done, speculative stretches included --,
  * [4] overflow retries, [5] reads that outgrew their output slot and [6] graph walks that outgrew the
- * visited list in the attempts that were redone; [7] the last lane-per-chunk pass of correct::one (forward
- * scan cut into units at predictable states): units in the low 32 bits, reads handed back to the
- * group kernel because two predictions in a row missed in the high 32 bits; 0 = that form did not run        */
+ * visited list in the attempts that were redone; [7] the last lane-per-chunk pass (forward scan cut into units at
+ * predictable states): units in bits 0-31, reads handed back to the group kernel in bits 32-55
+ * (three predictions in a row missed, a list overflowed), and in bits 56-63 the unit records the replay found
+ * unwritten (an invariant: always 0; the suites assert it); 0 = that form did not run                          */
 int brx_chain_last_stats(const brx_chain_t *chain, uint64_t *stats8);
 void brx_chain_free(brx_chain_t *chain);
 void brx_buf_free(void *p);

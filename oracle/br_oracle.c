@@ -1563,6 +1563,10 @@ typedef struct {
     uint64_t fixes;        /* per thread */
     uint8_t *counts;       /* counting job */
     int k;
+    const uint8_t *expect;       /* checking job: somebody else's corrected reads, may be NULL */
+    const uint64_t *expect_off;
+    uint64_t mismatches;         /* per thread: reads whose bytes differ from `expect` */
+    uint32_t first_bad;          /* per thread: the lowest such read (UINT32_MAX: none) */
 } mt_job;
 
 static void *mt_correct_worker(void *arg)
@@ -1580,6 +1584,14 @@ static void *mt_correct_worker(void *arg)
             size_t n;
             uint8_t *cbuf = bro_correct_record(ms, j->n_methods, j->two_side, j->bases + j->offsets[r],
                                                (size_t)(j->offsets[r + 1] - j->offsets[r]), &n);
+            if (j->expect) {
+                const uint64_t e0 = j->expect_off[r], e1 = j->expect_off[r + 1];
+                if (e1 - e0 != (uint64_t)n || (n && memcmp(cbuf, j->expect + e0, n) != 0)) {
+                    j->mismatches++;
+                    if (r < j->first_bad)
+                        j->first_bad = r;
+                }
+            }
             free(cbuf);
             if (j->out_lens)
                 j->out_lens[r] = n;
@@ -1595,9 +1607,27 @@ static void *mt_correct_worker(void *arg)
 
 /* corrects every read with the method chain on n_threads threads; returns total corrected bytes,
  * out_lens[r] (optional) = corrected length of read r, *fixes (optional) = Some(..) returns      */
+uint64_t bro_correct_batch_mt_check(const bro_solid *set, const int *methods, int n_methods, int c, int max_search,
+                                    int two_side, const uint8_t *bases, const uint64_t *offsets, uint32_t n_reads,
+                                    int n_threads, uint64_t *out_lens, uint64_t *fixes, const uint8_t *expect,
+                                    const uint64_t *expect_off, uint64_t *n_mismatch, uint32_t *first_bad);
+
 uint64_t bro_correct_batch_mt(const bro_solid *set, const int *methods, int n_methods, int c, int max_search,
                               int two_side, const uint8_t *bases, const uint64_t *offsets, uint32_t n_reads,
                               int n_threads, uint64_t *out_lens, uint64_t *fixes)
+{
+    return bro_correct_batch_mt_check(set, methods, n_methods, c, max_search, two_side, bases, offsets, n_reads, n_threads,
+                                      out_lens, fixes, NULL, NULL, NULL, NULL);
+}
+
+/* the same, and every corrected read is compared with somebody else's answer on the way (expect / expect_off, read r at
+ * expect[expect_off[r] .. expect_off[r + 1])): *n_mismatch = reads that differ, *first_bad = the lowest of them
+ * (UINT32_MAX: none).  This is how a GPU run of 1e5 reads is checked against the oracle read by read without keeping a
+ * second gigabyte of corrected bases around (tests/, bench.py's cpu_baseline leg).                                      */
+uint64_t bro_correct_batch_mt_check(const bro_solid *set, const int *methods, int n_methods, int c, int max_search,
+                                    int two_side, const uint8_t *bases, const uint64_t *offsets, uint32_t n_reads,
+                                    int n_threads, uint64_t *out_lens, uint64_t *fixes, const uint8_t *expect,
+                                    const uint64_t *expect_off, uint64_t *n_mismatch, uint32_t *first_bad)
 {
     if (n_threads < 1)
         n_threads = 1;
@@ -1619,16 +1649,27 @@ uint64_t bro_correct_batch_mt(const bro_solid *set, const int *methods, int n_me
         jobs[t].block = 16;
         jobs[t].cursor = &cursor;
         jobs[t].out_lens = out_lens;
+        jobs[t].expect = expect_off ? expect : NULL;
+        jobs[t].expect_off = expect_off;
+        jobs[t].first_bad = UINT32_MAX;
         pthread_create(&th[t], NULL, mt_correct_worker, &jobs[t]);
     }
-    uint64_t total = 0, fx = 0;
+    uint64_t total = 0, fx = 0, bad = 0;
+    uint32_t fb = UINT32_MAX;
     for (int t = 0; t < n_threads; t++) {
         pthread_join(th[t], NULL);
         total += jobs[t].out_bases;
         fx += jobs[t].fixes;
+        bad += jobs[t].mismatches;
+        if (jobs[t].first_bad < fb)
+            fb = jobs[t].first_bad;
     }
     if (fixes)
         *fixes = fx;
+    if (n_mismatch)
+        *n_mismatch = bad;
+    if (first_bad)
+        *first_bad = fb;
     free(jobs);
     free(th);
     return total;

@@ -14,7 +14,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 import subprocess
-from typing import Iterable, List, Sequence, Tuple
+from typing import Iterable, List, Optional, Sequence, Tuple
 
 import numpy as np
 
@@ -83,6 +83,8 @@ def lib():
                                               C.POINTER(C.c_int), C.POINTER(C.c_int)]),
         "bro_correct_batch_mt": (C.c_uint64, [vp, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.c_int, vp, vp,
                                               C.c_uint32, C.c_int, vp, u64p]),
+        "bro_correct_batch_mt_check": (C.c_uint64, [vp, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.c_int, vp, vp,
+                                                    C.c_uint32, C.c_int, vp, u64p, vp, vp, u64p, C.POINTER(C.c_uint32)]),
         "bro_count_batch_mt": (None, [vp, C.c_int, vp, vp, C.c_uint32, C.c_int]),
     }
     for name, (res, args) in sig.items():
@@ -291,16 +293,34 @@ def correct_batch_mt(solid: Solid, methods: Sequence[str], bases: np.ndarray, of
                      max_search: int = 7, two_side: bool = False, threads: int = 1):
     """the chain over every read on `threads` pthreads (bench.py's CPU baseline): returns (corrected lengths per
     read, total corrected bytes, fixes); the corrected bytes themselves are dropped."""
+    lens, total, fixes, _, _ = correct_batch_mt_check(solid, methods, bases, offsets, None, None, confirm, max_search, two_side,
+                                                      threads)
+    return lens, total, fixes
+
+
+def correct_batch_mt_check(solid: Solid, methods: Sequence[str], bases: np.ndarray, offsets: np.ndarray,
+                           expect: Optional[np.ndarray], expect_off: Optional[np.ndarray], confirm: int = 5,
+                           max_search: int = 7, two_side: bool = False, threads: int = 1):
+    """correct_batch_mt, and every corrected read is compared on the way with somebody else's answer (expect: uint8,
+    expect_off: uint64[n+1]): returns (lens, total, fixes, reads that differ, the lowest of them or None)."""
     bases = np.ascontiguousarray(bases, dtype=np.uint8)
     offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
     n = offsets.size - 1
     ids = (C.c_int * len(methods))(*[METHODS[m] for m in methods])
     lens = np.zeros(max(n, 1), dtype=np.uint64)
     fixes = C.c_uint64(0)
-    total = lib().bro_correct_batch_mt(solid._h, ids, len(methods), confirm, max_search, 1 if two_side else 0,
-                                       bases.ctypes.data, offsets.ctypes.data, n, threads, lens.ctypes.data,
-                                       C.byref(fixes))
-    return lens[:n], int(total), int(fixes.value)
+    bad = C.c_uint64(0)
+    first = C.c_uint32(0xffffffff)
+    ep = eo = None
+    if expect_off is not None:
+        expect = np.ascontiguousarray(expect, dtype=np.uint8)
+        expect_off = np.ascontiguousarray(expect_off, dtype=np.uint64)
+        assert expect_off.size == n + 1 and int(expect_off[-1]) <= expect.size
+        ep, eo = expect.ctypes.data, expect_off.ctypes.data
+    total = lib().bro_correct_batch_mt_check(solid._h, ids, len(methods), confirm, max_search, 1 if two_side else 0,
+                                             bases.ctypes.data, offsets.ctypes.data, n, threads, lens.ctypes.data,
+                                             C.byref(fixes), ep, eo, C.byref(bad), C.byref(first))
+    return lens[:n], int(total), int(fixes.value), int(bad.value), (None if first.value == 0xffffffff else int(first.value))
 
 
 def count_reads_mt(k: int, bases: np.ndarray, offsets: np.ndarray, threads: int = 1) -> np.ndarray:

@@ -41,7 +41,7 @@ def test_fixture_reads_any_chunking(raw_reads, solid_fixture_bytes, lane_env, ch
         om = O.build_methods(ref, names, 5, 7)
         for r, g in zip(reads, got):
             assert g == O.correct_record(om, r, two_side)
-        assert st["lane_units"] >= len(reads)
+        assert st["lane_units"] >= len(reads) and st["lane_unwritten_units"] == 0
         if chunk is not None and chunk <= 256:
             assert st["lane_units"] > 20 * len(reads)
         assert st["fixes"] > 0
@@ -213,3 +213,41 @@ def test_gap_size_walks_over_repeats(lane_env):
         bad = [i for i, (r, x) in enumerate(zip(reads, got)) if x != O.correct_record(om, r, True)]
         assert not bad, (names, bad[:10])
         assert chain.last_stats()["lane_units"] > 0
+
+
+def test_two_chains_on_two_threads_share_a_fresh_successor_table(lane_env):
+    """The successor table of the walking lane forms belongs to the SET and is built by whichever chain walks first; a
+    second chain on the same set -- its own stream, another host thread (include/brx.h: only calls on ONE chain are
+    serialised) -- must not read it half written.  Two threads start Graph / GapSize chains on a freshly indexed set at
+    the same moment, several times over fresh sets; every read equals the oracle's."""
+    import threading
+    lane_env(128, 2)
+    k = 19
+    cfg = synth.config(genome_len=60_000, read_len=4_000)
+    g = synth.genome_host(cfg)
+    bases, offs = synth.reads_host(cfg, g, 0, 600)
+    reads = [bases[int(offs[i]):int(offs[i + 1])].tobytes() for i in range(600)]
+    ref = O.Solid.sparse_from_count(k, reads, 2)
+    want = {m: [O.correct_record(O.build_methods(ref, [m], 5, 7), r, True) for r in reads] for m in ("graph", "gap_size")}
+    for rep in range(4):
+        gs = br_amd.Pcon.from_count(reads, k, 2)  # a fresh set: no successor table yet
+        chains = [br_amd.Chain(gs, [(m, 5, 7)], two_side=True) for m in ("graph", "gap_size")]
+        out, errs = [None, None], []
+        gate = threading.Barrier(2)
+
+        def work(j):
+            try:
+                gate.wait()
+                out[j] = chains[j].correct_reads(reads)
+            except Exception as e:  # noqa: BLE001
+                errs.append(e)
+        th = [threading.Thread(target=work, args=(j,)) for j in range(2)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        assert not errs, errs
+        for j, m in enumerate(("graph", "gap_size")):
+            assert chains[j].last_stats()["lane_units"] > 0
+            bad = [i for i in range(len(reads)) if out[j][i] != want[m][i]]
+            assert not bad, (rep, m, bad[:5])

@@ -150,6 +150,69 @@ def test_sample_of_reads_matches_oracle(job):
         assert st["fixes"] > (10_000_000 if methods[0] in ("one", "gap_size") else 500_000)
 
 
+def _threads():
+    import os
+    try:
+        return max(1, min(len(os.sched_getaffinity(0)), 16))
+    except AttributeError:
+        return 8
+
+
+def test_config1_every_read_vs_oracle(job):
+    """BASELINE configs[1] as bench.py runs it -- One, forward + reverse, all 100 000 reads -- compared with the oracle
+    READ BY READ (16 s on 16 host threads; `O.correct_batch_mt_check` compares inside its workers).  The lane form's
+    correctness hangs on rare events (a missed sync point is a handful per million units, a read handed back one in
+    100 000) that a sample of 62 reads never meets at this size.  And brx_chain_last_stats' `fixes` are the committed
+    ones: equal to the oracle's count (speculative units and stretches scanned twice used to be counted too)."""
+    import torch
+    stream = job["stream"]
+    osolid = O.Solid.wrap(K, job["solid"].export_bits())
+    d_out = torch.empty(int(job["total"] * 1.05) + (1 << 20), dtype=torch.uint8, device="cuda")
+    d_oo = torch.empty(N_READS + 1, dtype=torch.int64, device="cuda")
+    chain = br_amd.Chain(job["solid"], [("one", 5, 7)], two_side=False)
+    tot = chain.correct_batch_device(job["bases"].data_ptr(), job["offsets"].data_ptr(), N_READS, job["total"],
+                                     d_out.data_ptr(), d_out.numel(), d_oo.data_ptr(), stream)
+    st = chain.last_stats()
+    assert st["lane_units"] > 0, "the forward pass did not run in lane form"
+    assert st["lane_unwritten_units"] == 0
+    bases = job["bases"][:job["total"]].cpu().numpy()
+    offs = job["offsets"].cpu().numpy().astype(np.uint64)
+    got, got_off = d_out[:tot].cpu().numpy(), d_oo.cpu().numpy().astype(np.uint64)
+    _, want_total, want_fixes, n_bad, first_bad = O.correct_batch_mt_check(osolid, ["one"], bases, offs, got, got_off, 5, 7,
+                                                                           False, _threads())
+    assert n_bad == 0, f"{n_bad} of {N_READS} reads differ from the oracle, first: read {first_bad}"
+    assert want_total == tot
+    assert st["fixes"] == want_fixes, (st["fixes"], want_fixes)
+
+
+@pytest.mark.parametrize("method", ["graph", "gap_size"])
+def test_config1_walking_lane_forms_10000_reads_vs_oracle(job, method):
+    """the lane forms of the walking correctors (solidity mask on, the default) on 10 000 full-size reads, every read
+    against the oracle, forward + reverse; committed fixes equal the oracle's count"""
+    import torch
+    stream = job["stream"]
+    n = 10_000
+    osolid = O.Solid.wrap(K, job["solid"].export_bits())
+    off = job["offsets"][:n + 1].contiguous()
+    nb = int(off[-1].item())
+    d_out = torch.empty(int(nb * 1.05) + (1 << 20), dtype=torch.uint8, device="cuda")
+    d_oo = torch.empty(n + 1, dtype=torch.int64, device="cuda")
+    chain = br_amd.Chain(job["solid"], [(method, 5, 7)], two_side=False)
+    tot = chain.correct_batch_device(job["bases"].data_ptr(), off.data_ptr(), n, nb, d_out.data_ptr(), d_out.numel(),
+                                     d_oo.data_ptr(), stream)
+    st = chain.last_stats()
+    assert st["lane_units"] > 0, "the forward pass did not run in lane form"
+    assert st["lane_unwritten_units"] == 0
+    bases = job["bases"][:nb].cpu().numpy()
+    offs = off.cpu().numpy().astype(np.uint64)
+    got, got_off = d_out[:tot].cpu().numpy(), d_oo.cpu().numpy().astype(np.uint64)
+    _, want_total, want_fixes, n_bad, first_bad = O.correct_batch_mt_check(osolid, [method], bases, offs, got, got_off, 5, 7,
+                                                                           False, _threads())
+    assert n_bad == 0, f"{method}: {n_bad} of {n} reads differ from the oracle, first: read {first_bad}"
+    assert want_total == tot
+    assert st["fixes"] == want_fixes, (st["fixes"], want_fixes)
+
+
 def test_more_than_2_31_kmers_in_one_counter():
     """2.3 Gbp in one batch: key offsets beyond 2^31 (a sign-extended lane read once sent the final counting
     pass into an endless loop there).  Property check instead of the oracle: at 50x coverage nearly every

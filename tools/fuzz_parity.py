@@ -12,6 +12,7 @@ import br_amd
 from br_amd import _lib
 from oracle import oracle as O
 
+import json, collections
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 only_case = int(sys.argv[3]) if len(sys.argv) > 3 else 0
@@ -52,6 +53,85 @@ def make_reads(glen, n_reads, rl_lo, rl_hi, err):
             out[int(rng.integers(0, len(out)))] = ord("N")
         reads.append(bytes(out))
     return reads
+
+
+history = collections.deque(maxlen=9)  # this case's settings and the eight before it (process state carried over?)
+REPORT_DIR = os.environ.get("FUZZ_REPORT_DIR", os.path.join(ROOT, "gpurun_out"))
+
+
+def first_diff(a: bytes, b: bytes) -> int:
+    m = min(len(a), len(b))
+    for x in range(m):
+        if a[x] != b[x]:
+            return x
+    return m if len(a) != len(b) else -1
+
+
+def run_chain(gs, names, c, ms, two_side, reads, env_over=None):
+    """the same job once more in this process, optionally with some switches changed"""
+    saved = {}
+    for key, v in (env_over or {}).items():
+        saved[key] = os.environ.get(key)
+        if v == "":
+            os.environ.pop(key, None)
+        else:
+            os.environ[key] = v
+    try:
+        return br_amd.Chain(gs, [(m, c, ms) for m in names], two_side=two_side).correct_reads(reads)
+    finally:
+        for key, v in saved.items():
+            if v is None:
+                os.environ.pop(key, None)
+            else:
+                os.environ[key] = v
+
+
+def report_mismatch(desc, case, seed, gs, ref, names, c, ms, two_side, reads, got, bad, rebuild):
+    """Everything needed to explain a mismatch without seeing it again, written to a file that is kept: the reads that
+    differ (input, want, got, first differing offset), the settings of this case and the eight before it, and what the
+    same process answers when the job is asked again: unchanged, with the lane forms off, with a freshly built set, and
+    pass by pass (each pass of the chain alone, fed the oracle's intermediate: which pass diverges first)."""
+    om = O.build_methods(ref, names, c, ms)
+    rep = {"seed": seed, "case": case, "desc": desc, "previous_cases": list(history), "reads": [], "reruns": {}, "passes": []}
+    for ri in bad[:8]:
+        want = O.correct_record(om, reads[ri], two_side)
+        rep["reads"].append({"read": ri, "len": len(reads[ri]), "first_diff": first_diff(want, got[ri]), "input": reads[ri].decode("latin1"),
+                             "want": want.decode("latin1"), "got": got[ri].decode("latin1")})
+    want_all = [O.correct_record(om, r, two_side) for r in reads]
+
+    def differing(out):
+        return [ri for ri in range(len(reads)) if out[ri] != want_all[ri]]
+    try:
+        rep["reruns"]["same_settings_same_set"] = differing(run_chain(gs, names, c, ms, two_side, reads))
+        rep["reruns"]["lane_off"] = differing(run_chain(gs, names, c, ms, two_side, reads, {"BRX_LANE": "0"}))
+        rep["reruns"]["lane_mask_off"] = differing(run_chain(gs, names, c, ms, two_side, reads, {"BRX_LANE_MASK": "0"}))
+        rep["reruns"]["lane_walk_off"] = differing(run_chain(gs, names, c, ms, two_side, reads, {"BRX_LANE_WALK": "0"}))
+        gs2 = rebuild()
+        rep["reruns"]["fresh_set_popcount"] = [int(gs2.popcount()), int(ref.popcount())]
+        rep["reruns"]["same_settings_fresh_set"] = differing(run_chain(gs2, names, c, ms, two_side, reads))
+        # pass by pass: forward passes of the chain in order, then (unless two_side) the same over the reversed reads --
+        # every pass is the GPU chain [method] alone, forward only, on the ORACLE's intermediate of the reads that differed
+        cur = [reads[ri] for ri in bad[:8]]
+        for direction in range(1 if two_side else 2):
+            if direction == 1:
+                cur = [x[::-1] for x in cur]
+            for m in names:
+                o1 = O.build_methods(ref, [m], c, ms)
+                want1 = [O.correct_record(o1, x, True) for x in cur]
+                got1 = run_chain(gs, [m], c, ms, True, cur)
+                got1_off = run_chain(gs, [m], c, ms, True, cur, {"BRX_LANE": "0"})
+                rep["passes"].append({"dir": direction, "method": m,
+                                      "differs": [j for j in range(len(cur)) if got1[j] != want1[j]],
+                                      "differs_lane_off": [j for j in range(len(cur)) if got1_off[j] != want1[j]]})
+                cur = want1
+    except Exception as e:  # the report must come out whatever the re-runs do
+        rep["rerun_error"] = repr(e)
+    os.makedirs(REPORT_DIR, exist_ok=True)
+    path = os.path.join(REPORT_DIR, f"fuzz_mismatch_seed{seed}_case{case}.json")
+    with open(path, "w") as f:
+        json.dump(rep, f, indent=1)
+    print("READ MISMATCH", desc, "\nreport:", path, "\nreads:", bad[:8], "first_diff:", [x["first_diff"] for x in rep["reads"]],
+          "\nreruns:", rep["reruns"], "\npasses:", rep["passes"], flush=True)
 
 
 t_end = time.time() + budget
@@ -122,6 +202,15 @@ while time.time() < t_end:
         gs = cnt.finish(a)
     ref = O.Solid.sparse_from_count(k, counted, a) if k >= 17 else O.Solid.from_count(k, O.count_reads(k, counted), a)
     desc = f"case {case}: k={k} a={a} c={c} ms={ms} reads={n_reads} chain={names} two_side={two_side} strat={strategy} {env}"
+    history.append(desc)
+
+    def rebuild():
+        if continue_presence:
+            return br_amd.Pcon.from_fasta(counted, k, batch=batch)
+        cnt2 = br_amd.Counter(k, 0, strategy)
+        if counted:
+            cnt2.add_reads(counted)
+        return cnt2.finish(a)
     if gs.popcount() != ref.popcount():
         print("SET MISMATCH", desc); sys.exit(1)
     om = O.build_methods(ref, names, c, ms)
@@ -138,17 +227,20 @@ while time.time() < t_end:
             for ri in bad[:3]:
                 print(" read", ri, len(reads[ri]), reads[ri][:600], "\n want", O.correct_record(om, reads[ri], two_side)[:600], "\n got ", got2[ri][:600])
     try:
-        got = br_amd.Chain(gs, [(m, c, ms) for m in names], two_side=two_side).correct_reads(reads)
+        the_chain = br_amd.Chain(gs, [(m, c, ms) for m in names], two_side=two_side)
+        got = the_chain.correct_reads(reads)
+        if the_chain.last_stats()["lane_unwritten_units"]:
+            print("INVARIANT BROKEN: unit records never written by the lane pass", the_chain.last_stats(), desc); sys.exit(1)
+        del the_chain
     except _lib.BrxError as e:
         if "does not terminate" in str(e):   # greedy can spin in the reference too: not comparable
             print("skip (non-terminating greedy)", desc); continue
         print("ERROR", e, desc); sys.exit(1)
-    for ri, (r, g_) in enumerate(zip(reads, got)):
-        want = O.correct_record(om, r, two_side)
-        if g_ != want:
-            print("READ MISMATCH", desc, "\nread", ri, "of length", len(r), ":", r[:400], "\nwant:", want[:400], "\ngot: ", g_[:400])
-            if only_case:
-                continue
+    bad = [ri for ri, (r, g_) in enumerate(zip(reads, got)) if g_ != O.correct_record(om, r, two_side)]
+    if bad:
+        report_mismatch(desc, case, seed, gs, ref, names, c, ms, two_side, reads, got, bad, rebuild)
+        if not only_case:
             sys.exit(1)
+        continue
     print("ok", desc, flush=True)
 print(f"{case} cases, no mismatch")
