@@ -382,7 +382,9 @@ def main():
             "e2e": e2e,
             "host_8192": host,
         }
-        print(json.dumps(line))
+        print(json.dumps(line), flush=True)
+        if checks.get("parity_mismatches"):
+            sys.exit(3)  # a rate for bytes that differ from the reference's is not a result
     if exchanger is not None and hasattr(exchanger, "close"):
         exchanger.close()
     if multi:
