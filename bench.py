@@ -269,10 +269,35 @@ def main():
     # every rank must hold the same set, and roughly one solid k-mer per genome position and strand-pair
     checks = {"solid_per_genome_base": round(solid_bits / genome_len, 3)}
     if world > 1:
-        lo = int(reduce_scalar(solid_bits, dist.ReduceOp.MIN, torch.int64))
-        hi = int(reduce_scalar(solid_bits, dist.ReduceOp.MAX, torch.int64))
-        checks["set_popcount_identical_across_ranks"] = bool(lo == hi)
-        checks["rccl_ranks"] = world if not args.rehearse_on_one_gpu else 0
+        # Every rank must end with THE SAME set -- the one thing the exchange is for.  One all-gather of a fingerprint per
+        # rank: popcount plus two order-independent 64-bit folds of the set's members (wrapping sums of k and of k * k over
+        # the solid-hash list; over the bit vector's words, weighted by their index, when the build kept no list).  The
+        # gather runs over the job's own backend, so the ranks that answer are also the count of ranks RCCL really joined.
+        kl = gs.keylist_device(stream)
+        if kl is not None and kl[1] > 0:
+            keys = brx_dist.device_view(kl[0], kl[1] * 8).view(torch.int64)
+            f1, f2, how = int(keys.sum().item()), int((keys * keys).sum().item()), "solid-hash list"
+        else:
+            ptr, nbytes = gs.device_bits()
+            words = brx_dist.device_view(ptr, nbytes).view(torch.int64)
+            f1 = int(words.sum().item())
+            f2 = 0
+            step_w = 1 << 24
+            for lo_w in range(0, words.numel(), step_w):  # (index weights in slices: no second 16 GiB tensor)
+                part = words[lo_w:lo_w + step_w]
+                f2 = (f2 + int((part * torch.arange(lo_w + 1, lo_w + 1 + part.numel(), device=part.device)).sum().item())) & ((1 << 64) - 1)
+            how = "bit vector words"
+        to_i64 = lambda v: v - (1 << 64) if v >= (1 << 63) else v
+        mine = torch.tensor([to_i64(int(solid_bits)), to_i64(f1 & ((1 << 64) - 1)), to_i64(f2 & ((1 << 64) - 1))], dtype=torch.int64,
+                            device="cpu" if args.rehearse_on_one_gpu else "cuda")
+        gathered = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(gathered, mine)
+        prints = [tuple(int(x) for x in g.cpu().tolist()) for g in gathered]
+        checks["set_agree"] = bool(all(p_ == prints[0] for p_ in prints))
+        checks["set_fingerprint"] = {"of": how, "popcount": prints[0][0], "fold_sum": prints[0][1] & ((1 << 64) - 1),
+                                     "fold_sum_sq": prints[0][2] & ((1 << 64) - 1)}
+        checks["set_popcount_identical_across_ranks"] = bool(len({p_[0] for p_ in prints}) == 1)
+        checks["rccl_ranks"] = (len(prints) if dist.get_backend() == "nccl" else 0)
     min_fixes = 0.01 * total if args.methods == ["one"] else 0  # One repairs most isolated errors; Greedy few
     checks["plausible"] = bool(0.9 < solid_bits / genome_len < 1.3 and stats["fixes"] > min_fixes)
 
@@ -385,6 +410,14 @@ def main():
         print(json.dumps(line), flush=True)
         if checks.get("parity_mismatches"):
             sys.exit(3)  # a rate for bytes that differ from the reference's is not a result
+    # N > 1: a job whose ranks do not hold the same set, or that RCCL did not carry with all N ranks, has no rate either
+    # (every rank computes the same verdict from the same gather: all of them leave with it)
+    if world > 1 and (not checks.get("set_agree") or (not args.rehearse_on_one_gpu and checks.get("rccl_ranks") != world)):
+        print("bench.py: rank %d: the ranks' sets differ or RCCL ranks != %d: %s" % (rank, world, checks), file=sys.stderr)
+        if exchanger is not None and hasattr(exchanger, "close"):
+            exchanger.close()
+        dist.destroy_process_group()
+        sys.exit(4)
     if exchanger is not None and hasattr(exchanger, "close"):
         exchanger.close()
     if multi:
@@ -556,7 +589,49 @@ def host_8192(args, d_bases, d_off, n_reads, gs):
             res[kind] = {"gbases_per_s": round(nb / dt / 1e9, 3), "ms_per_batch": round(dt / n_b * 1e3, 2)}
             for ptr in keep:
                 L.brx_host_free(ptr)
-        res["value"] = res["pinned"]["gbases_per_s"]
+        # the same batches, page-locked, through brx_chain_correct_batch_async / _wait: ONE host thread rotating over
+        # three chains of the set, so that a batch's upload, another's passes and a third's download overlap
+        # (the double-buffered form of run_correction's batch loop)
+        n_ch, rounds = 3, 3
+        chains = [br_amd.Chain(gs, [(m, args.confirm, 7) for m in args.methods], two_side=False) for _ in range(n_ch)]
+        bufs, keep = [], []
+        for b in range(n_b + 1):
+            lo, hi = int(off_all[b * per]), int(off_all[(b + 1) * per])
+            offs = np.ascontiguousarray(off_all[b * per:(b + 1) * per + 1] - off_all[b * per])
+            ptr = L.brx_host_alloc(hi - lo)
+            keep.append(ptr)
+            C.memmove(ptr, bases_all[lo:hi].ctypes.data, hi - lo)
+            bufs.append((ptr, offs, hi - lo))
+        ob, oo = C.POINTER(C.c_uint8)(), C.POINTER(C.c_uint64)()
+        def submit(ch, bf):
+            _lib.check(L.brx_chain_correct_batch_async(ch._h, bf[0], bf[1].ctypes.data, per))
+        def collect(ch):
+            _lib.check(L.brx_chain_correct_batch_wait(ch._h, C.byref(ob), C.byref(oo)))
+            L.brx_buf_free(ob)
+            L.brx_buf_free(oo)
+        for ch in chains:                     # warm-up: every chain's workspace
+            submit(ch, bufs[n_b])
+        for ch in chains:
+            collect(ch)
+        seq = [bufs[b % n_b] for b in range(n_b * rounds)]
+        t0 = time.perf_counter()
+        for j, bf in enumerate(seq):
+            ch = chains[j % n_ch]
+            if j >= n_ch:
+                collect(ch)
+            submit(ch, bf)
+        for j in range(min(n_ch, len(seq))):
+            collect(chains[(len(seq) - min(n_ch, len(seq)) + j) % n_ch])
+        dt = time.perf_counter() - t0
+        nb = sum(bf[2] for bf in seq)
+        res["pinned_async_3_chains"] = {"gbases_per_s": round(nb / dt / 1e9, 3), "ms_per_batch": round(dt / len(seq) * 1e3, 2),
+                                        "batches": len(seq)}
+        for ptr in keep:
+            L.brx_host_free(ptr)
+        del chains
+        res["value"] = res["pinned_async_3_chains"]["gbases_per_s"]
+        res["value_is"] = "page-locked batches, one host thread, three chains in flight (brx_chain_correct_batch_async / _wait); " \
+                          "`pinned` is the single synchronous call"
         res["unit"] = "Gbases/s"
         return res
     except Exception as e:

@@ -95,6 +95,8 @@ SIGNATURES = {
     "brx_comm_free": (None, [_vp]),
     "brx_chain_new": (C.c_int, [_vp, C.POINTER(Method), C.c_uint32, C.c_bool, _pp]),
     "brx_chain_correct_batch": (C.c_int, [_vp, _vp, _vp, C.c_uint32, C.POINTER(_u8p), C.POINTER(_u64p)]),
+    "brx_chain_correct_batch_async": (C.c_int, [_vp, _vp, _vp, C.c_uint32]),
+    "brx_chain_correct_batch_wait": (C.c_int, [_vp, C.POINTER(_u8p), C.POINTER(_u64p)]),
     "brx_chain_correct_batch_device": (C.c_int, [_vp, _vp, _vp, C.c_uint32, C.c_uint64, _vp, C.c_uint64, _vp,
                                                  _u64p, _vp]),
     "brx_chain_last_stats": (C.c_int, [_vp, _u64p]),

@@ -56,6 +56,29 @@ class Chain:
             L.brx_buf_free(oo)
         return out, out_off
 
+    def correct_batch_async(self, bases: np.ndarray, offsets: np.ndarray) -> None:
+        """brx_chain_correct_batch_async: starts the batch and returns; `correct_batch_wait` collects it.  One batch in
+        flight per chain -- a host overlaps batches by rotating over two or three chains of the same set."""
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        self._inflight = (bases, offsets)  # the library reads them until _wait returns
+        _lib.check(_lib.lib().brx_chain_correct_batch_async(self._h, bases.ctypes.data, offsets.ctypes.data, offsets.size - 1))
+
+    def correct_batch_wait(self) -> Tuple[np.ndarray, np.ndarray]:
+        L = _lib.lib()
+        ob, oo = C.POINTER(C.c_uint8)(), C.POINTER(C.c_uint64)()
+        try:
+            _lib.check(L.brx_chain_correct_batch_wait(self._h, C.byref(ob), C.byref(oo)))
+            n = self._inflight[1].size - 1
+            out_off = np.ctypeslib.as_array(oo, shape=(n + 1,)).copy()
+            total = int(out_off[-1])
+            out = np.ctypeslib.as_array(ob, shape=(max(total, 1),))[:total].copy()
+        finally:
+            self._inflight = None
+            L.brx_buf_free(ob)
+            L.brx_buf_free(oo)
+        return out, out_off
+
     def correct_reads(self, reads: Sequence[bytes]) -> List[bytes]:
         bases, offs = pack_reads(reads)
         out, oo = self.correct_batch(bases, offs)

@@ -2353,9 +2353,22 @@ static int correct_batch_device_locked(brx_chain_t *ch, const uint8_t *d_bases, 
                 p.max_search = 0;
                 p.g_dim = 0;
                 p.g_lds_bytes = 0;
-                if ((mth == BRX_ONE || mth == BRX_GRAPH || mth == BRX_GAP_SIZE) && dir == 0 && !p.flip) {
-                    // forward passes of One, Graph and GapSize: one lane per chunk of a read (brx_onelane.hip) where that
-                    // form applies
+                // BRX_LANE_REV (1 / 0; default: by index size): the REVERSE passes of Graph and GapSize in lane form too.
+                // Their scan meets hardly a solid k-mer (the read is read back to front, not complemented), so over the
+                // solidity mask it is bit runs of sixteen positions a round -- but the rare trigger runs error_len to the
+                // END OF THE READ (hundreds of rounds of one lane, whose wave waits for it) and GapSize then walks thousands
+                // of fixed steps, which the lanes hand back.  Measured (profiles/r4c_*): at 2^25 index lines the lane form
+                // LOSES (graph 65.6 -> 75.4 ms per Gbp fwd+rev, gap_size 92 -> 211 with 1 845 reads redone by the list
+                // kernel); at 2^29 lines (the set every GPU of the 8-GPU jobs holds) it WINS: the 64-lane group kernels
+                // lose their L2-resident occupancy bits there and take ~180 ms per 8 Gbp pass, graph + gap_size
+                // 932 -> 748 ms.  So: on past 2^26 lines, off below.  One's reverse pass stays with its 64-lane kernel.
+                const bool lane_rev_default = idx.lines != nullptr && 32u - idx.line_shift > 26u;
+                const char *e_rev = getenv("BRX_LANE_REV");
+                const bool lane_rev = e_rev && *e_rev ? *e_rev != '0' : lane_rev_default;
+                const bool lane_dir = dir == 0 ? !p.flip : (lane_rev && (mth == BRX_GRAPH || mth == BRX_GAP_SIZE));
+                if ((mth == BRX_ONE || mth == BRX_GRAPH || mth == BRX_GAP_SIZE) && lane_dir) {
+                    // forward passes of One, Graph and GapSize (and the reverse ones of the latter two): one lane per chunk
+                    // of a read (brx_onelane.hip) where that form applies
                     const LanePassInfo info{cur_staged ? ch->stage_bytes : total_bases, mth};
                     const int lst = lane_pass(ch, p, info, s);
                     if (lst != BRX_OK && lst != BRX_ERR_UNSUPPORTED)
@@ -2578,6 +2591,69 @@ int brx_chain_correct_batch(brx_chain_t *ch, const uint8_t *bases, const uint64_
     return BRX_OK;
 }
 
+// ---- one batch in flight per chain -----------------------------------------------------------------------------------
+// brx_chain_correct_batch is upload -> passes -> download, back to back on one stream: 82 MB up, ~3 ms of kernels,
+// 82 MB down per 8192-record batch, nothing overlapping (9 Gbases/s from page-locked memory against 36 for the passes
+// alone).  The overlap a host needs is BETWEEN batches -- the next one's upload under this one's kernels under the last
+// one's download -- and chains are the unit that owns a stream and a workspace.  So the asynchronous form is per chain:
+// _async starts the batch on a thread of the library and returns, _wait hands out its result; a host keeps two or three
+// chains of the same set busy in turn from ONE thread (INTEGRATION.md has the loop run_correction would use).
+namespace {
+struct AsyncJob {
+    std::thread th;
+    int status = BRX_OK;
+    uint8_t *ob = nullptr;
+    uint64_t *oo = nullptr;
+    std::string err;
+};
+} // namespace
+
+int brx_chain_correct_batch_async(brx_chain_t *ch, const uint8_t *bases, const uint64_t *offsets, uint32_t n_reads)
+{
+    if (!ch || !offsets || (!bases && n_reads)) {
+        set_error("null argument");
+        return BRX_ERR_ARG;
+    }
+    if (ch->async_job) {
+        set_error("chain already has a batch in flight: brx_chain_correct_batch_wait first (one per chain; use several chains)");
+        return BRX_ERR_ARG;
+    }
+    AsyncJob *job = new AsyncJob();
+    ch->async_job = job;
+    job->th = std::thread([ch, job, bases, offsets, n_reads] {
+        job->status = brx_chain_correct_batch(ch, bases, offsets, n_reads, &job->ob, &job->oo);
+        if (job->status != BRX_OK)
+            job->err = brx_last_error(); // (the message lives in this thread: carried over to the waiter)
+    });
+    return BRX_OK;
+}
+
+int brx_chain_correct_batch_wait(brx_chain_t *ch, uint8_t **out_bases, uint64_t **out_offsets)
+{
+    if (!ch || !out_bases || !out_offsets) {
+        set_error("null argument");
+        return BRX_ERR_ARG;
+    }
+    *out_bases = nullptr;
+    *out_offsets = nullptr;
+    AsyncJob *job = (AsyncJob *)ch->async_job;
+    if (!job) {
+        set_error("no batch in flight on this chain");
+        return BRX_ERR_ARG;
+    }
+    job->th.join();
+    ch->async_job = nullptr;
+    const int st = job->status;
+    if (st == BRX_OK) {
+        *out_bases = job->ob;
+        *out_offsets = job->oo;
+    } else {
+        set_error("%s", job->err.c_str());
+    }
+    delete job;
+    return st;
+}
+
 int brx_chain_last_stats(const brx_chain_t *ch, uint64_t *stats8)
 {
     if (!ch || !stats8)
@@ -2590,6 +2666,13 @@ void brx_chain_free(brx_chain_t *ch)
 {
     if (!ch)
         return;
+    if (ch->async_job) { // a batch still in flight: let it finish, drop its result
+        uint8_t *ob = nullptr;
+        uint64_t *oo = nullptr;
+        (void)brx_chain_correct_batch_wait(ch, &ob, &oo);
+        brx_buf_free(ob);
+        brx_buf_free(oo);
+    }
     if (ch->sub)
         brx_chain_free(ch->sub);
     ch->sub = nullptr;

@@ -182,6 +182,7 @@ struct brx_chain {
     void *lane_ws = nullptr; // workspace of the lane-per-chunk pass (brx_onelane.hip)
     uint8_t *h_in = nullptr; // page-locked bounce block for batches handed over in pageable memory
     uint64_t h_in_cap = 0;
+    void *async_job = nullptr; // a batch in flight (brx_chain_correct_batch_async), owned by the chain
     std::mutex mu;
 };
 

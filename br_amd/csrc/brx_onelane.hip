@@ -110,6 +110,21 @@ __device__ __forceinline__ uint64_t read_view(const PassParams &p, uint32_t r, c
     in = p.in + at;
     return at;
 }
+// A pass over reads stored back to front (p.flip: run_correction's reverse pass reads the forward pass's output
+// backwards, src/lib.rs:48-55; no reversed copy is ever made) sees LOGICAL base j at in[n - 1 - j].  Everything between
+// the packed copy and the replay works on logical positions; these three are the only places that touch the bytes.
+__device__ __forceinline__ uint8_t ld_logical(const uint8_t *in, uint32_t n, uint32_t j, bool flip) { return in[flip ? n - 1u - j : j]; }
+// logical bases j .. j+15 (all inside the read), first one in the lowest byte
+__device__ __forceinline__ uint4 ld16_logical(const uint8_t *in, uint32_t n, uint32_t j, bool flip)
+{
+    uint4 q;
+    if (!flip) {
+        __builtin_memcpy(&q, in + j, 16);
+        return q;
+    }
+    __builtin_memcpy(&q, in + (n - 16u - j), 16);
+    return make_uint4(__builtin_bswap32(q.w), __builtin_bswap32(q.z), __builtin_bswap32(q.y), __builtin_bswap32(q.x));
+}
 // first dword of read r in P: 16 bases per dword and five dwords of padding per read (the window prefetches ahead)
 __device__ __forceinline__ uint64_t pack_start(uint64_t in_at, uint32_t r) { return (in_at >> 4) + 5ull * r; }
 // first entry of unit jj (sync position q) of a read in an edit list: a quarter entry per base + 16 per unit.  Monotone
@@ -145,15 +160,14 @@ __global__ __launch_bounds__(256) void lane_pack_kernel(LaneArgs a)
             const uint32_t b = 16u * d;
             uint32_t w[4] = {0, 0, 0, 0};
             if (b + 16u <= n) {
-                uint4 q;
-                __builtin_memcpy(&q, in + b, 16);
+                const uint4 q = ld16_logical(in, n, b, a.p.flip);
                 w[0] = q.x;
                 w[1] = q.y;
                 w[2] = q.z;
                 w[3] = q.w;
             } else {
                 for (uint32_t t = 0; t < 16u && b + t < n; t++)
-                    w[t >> 2] |= (uint32_t)in[b + t] << (8u * (t & 3u));
+                    w[t >> 2] |= (uint32_t)ld_logical(in, n, b + t, a.p.flip) << (8u * (t & 3u));
             }
             // bytes b0..b3 of a word (b0 = first base) -> b0<<6 | b1<<4 | b2<<2 | b3 by one multiply
             uint32_t v = 0;
@@ -820,23 +834,22 @@ __global__ __launch_bounds__(256, MASK ? 6 : BRX_LANE_WAVES) void lane_kernel(La
     }
 }
 
-__device__ __forceinline__ void copy_bytes(uint8_t *dst, const uint8_t *src, uint32_t n)
+// logical bases [from, from + len) of a read of n bases -> dst
+__device__ __forceinline__ void copy_bytes(uint8_t *dst, const uint8_t *in, uint32_t n_read, uint32_t from, uint32_t len, bool flip)
 {
     // bytes up to the first 16-byte boundary of dst, then 16 bytes per lane (unaligned load, aligned store), then the tail
     uint32_t head = (uint32_t)((16u - (uint32_t)((uintptr_t)dst & 15u)) & 15u);
-    if (head > n)
-        head = n;
-    const uint32_t nv = (n - head) / 16u;
+    if (head > len)
+        head = len;
+    const uint32_t nv = (len - head) / 16u;
     for (uint32_t j = threadIdx.x; j < head; j += blockDim.x)
-        dst[j] = src[j];
+        dst[j] = ld_logical(in, n_read, from + j, flip);
     for (uint32_t v = threadIdx.x; v < nv; v += blockDim.x) {
         const uint32_t j = head + 16u * v;
-        uint4 q;
-        __builtin_memcpy(&q, src + j, 16);
-        *reinterpret_cast<uint4 *>(dst + j) = q;
+        *reinterpret_cast<uint4 *>(dst + j) = ld16_logical(in, n_read, from + j, flip);
     }
-    for (uint32_t j = head + 16u * nv + threadIdx.x; j < n; j += blockDim.x)
-        dst[j] = src[j];
+    for (uint32_t j = head + 16u * nv + threadIdx.x; j < len; j += blockDim.x)
+        dst[j] = ld_logical(in, n_read, from + j, flip);
 }
 
 // ---- successor table: next_nucs (mod.rs:118-128) of every indexed k-mer, worked out once --------------------------------
@@ -1546,15 +1559,13 @@ __global__ __launch_bounds__(AP_BS) void lane_apply_kernel(LaneArgs a)
                         uint32_t m = lo;
                         const uint32_t copied_end = e_os[m + 1] - 1u; // the fix's own base sits here
                         if (x1 - x0 == 16u && x1 <= copied_end) {
-                            uint4 q;
-                            __builtin_memcpy(&q, in + e_in[m] + (x0 - e_os[m]), 16);
-                            *reinterpret_cast<uint4 *>(ob + x0) = q;
+                            *reinterpret_cast<uint4 *>(ob + x0) = ld16_logical(in, n, e_in[m] + (x0 - e_os[m]), p.flip);
                         } else {
                             for (uint32_t x = x0; x < x1; x++) {
                                 while (x >= e_os[m + 1])
                                     m++;
                                 const uint32_t rel = x - e_os[m];
-                                ob[x] = x + 1u == e_os[m + 1] ? bit2nuc(e_raw[m] & 3u) : in[e_in[m] + rel];
+                                ob[x] = x + 1u == e_os[m + 1] ? bit2nuc(e_raw[m] & 3u) : ld_logical(in, n, e_in[m] + rel, p.flip);
                             }
                         }
                     }
@@ -1568,7 +1579,7 @@ __global__ __launch_bounds__(AP_BS) void lane_apply_kernel(LaneArgs a)
         if (!failed && n > cur_in) {
             const uint32_t len = n - cur_in;
             if (total + len <= slot)
-                copy_bytes(dst + total, in + cur_in, len);
+                copy_bytes(dst + total, in, n, cur_in, len, p.flip);
             total += len;
         }
         if (threadIdx.x == 0) {
@@ -1814,9 +1825,7 @@ __global__ __launch_bounds__(256) void lane_apply_walk_kernel(LaneArgs a)
                     uint32_t m = lo;
                     const uint32_t copied_end = e_os[m + 1] - (e_uc[m] & 0xffffu); // the fix's own bases start here
                     if (x1 - x0 == 16u && x1 <= copied_end) {
-                        uint4 q;
-                        __builtin_memcpy(&q, in + e_in[m] + (x0 - e_os[m]), 16);
-                        *reinterpret_cast<uint4 *>(ob + x0) = q;
+                        *reinterpret_cast<uint4 *>(ob + x0) = ld16_logical(in, n, e_in[m] + (x0 - e_os[m]), p.flip);
                     } else {
                         // (the word of written bases in hand is kept from byte to byte: a fix of a walking corrector writes
                         // several bases, and a load per byte was most of what this kernel cost beyond One's)
@@ -1826,7 +1835,7 @@ __global__ __launch_bounds__(256) void lane_apply_walk_kernel(LaneArgs a)
                                 m++;
                             const uint32_t rel = x - e_os[m], seglen = (e_pos[m] & 0x7fffffffu) - e_in[m];
                             if (rel < seglen) {
-                                ob[x] = in[e_in[m] + rel];
+                                ob[x] = ld_logical(in, n, e_in[m] + rel, p.flip);
                             } else {
                                 const uint32_t tb = rel - seglen; // base tb of the fix
                                 if (w_m != m || w_i != (tb >> 4)) {
@@ -1849,7 +1858,7 @@ __global__ __launch_bounds__(256) void lane_apply_walk_kernel(LaneArgs a)
         if (!failed && n > cur_in) {
             const uint32_t len = n - cur_in;
             if (total + len <= slot)
-                copy_bytes(dst + total, in + cur_in, len);
+                copy_bytes(dst + total, in, n, cur_in, len, p.flip);
             total += len;
         }
         if (threadIdx.x == 0) {
@@ -1942,7 +1951,7 @@ int lane_pass(brx_chain *ch, const PassParams &p, const LanePassInfo &info, hipS
 {
     // BRX_LANE=0: the group kernel only.  The window of a round shows 8 bases: look-aheads up to off + c + 1 <= 8.
     const bool walk = info.method != BRX_ONE;
-    if (env_u32("BRX_LANE", 1u) == 0u || p.flip || p.k > 31 || p.n_reads == 0)
+    if (env_u32("BRX_LANE", 1u) == 0u || p.k > 31 || p.n_reads == 0)
         return BRX_ERR_UNSUPPORTED;
     if (info.method != BRX_GRAPH && (p.c < 1 || p.c > 5)) // (Graph has no look-aheads; One and GapSize's One branch do)
         return BRX_ERR_UNSUPPORTED;

@@ -237,6 +237,14 @@ int brx_chain_new(const brx_set_t *set, const brx_method_t *methods, uint32_t n_
  * library; release with brx_buf_free.                                                       */
 int brx_chain_correct_batch(brx_chain_t *chain, const uint8_t *bases, const uint64_t *offsets, uint32_t n_reads,
                             uint8_t **out_bases, uint64_t **out_offsets);
+/* The same batch, started and collected in two calls, so that ONE host thread can keep several chains of a set busy:
+ * the next batch's upload runs under this one's kernels under the last one's download (a chain owns a stream and a
+ * workspace; batches on different chains overlap, a chain takes one batch at a time).  `bases` / `offsets` must stay
+ * valid until _wait returns; _wait blocks, returns what brx_chain_correct_batch would have returned and hands out the
+ * same callee-allocated buffers.  This is the loop run_correction's 8192-record batches map to (src/lib.rs:84-132):
+ * INTEGRATION.md shows it.  brx_chain_free waits for a batch still in flight.                                          */
+int brx_chain_correct_batch_async(brx_chain_t *chain, const uint8_t *bases, const uint64_t *offsets, uint32_t n_reads);
+int brx_chain_correct_batch_wait(brx_chain_t *chain, uint8_t **out_bases, uint64_t **out_offsets);
 /* same on device buffers: d_out (capacity out_cap bytes) and d_out_offsets (n_reads+1) are
  * caller-allocated; *out_total receives the number of corrected bytes.  Returns
  * BRX_ERR_OVERFLOW (with *out_total = needed) if out_cap is too small.  The call returns

@@ -149,3 +149,38 @@ def test_presence_set_from_fasta_stream(golden_dir, raw_reads, k):
         q = np.concatenate([np.array([O.seq2bit(r[i:i + k]) for r in raw_reads[:5] for i in range(0, 400, 7)], dtype=np.uint64),
                             rng.integers(0, 1 << (2 * k), 3000, dtype=np.uint64)])
         assert np.array_equal(gs.get_many(q), np.array([ref.get(int(x)) for x in q]))
+
+
+def test_async_batches_rotate_over_three_chains(raw_reads, solid_fixture_bytes):
+    """brx_chain_correct_batch_async / _wait: one host thread keeps three chains of a set busy in turn (the
+    double-buffered form of run_correction's batch loop, src/lib.rs:84-132).  Every batch equals the synchronous call
+    and the oracle; a second _async on a busy chain and a _wait on an idle one are refused; freeing a chain with a
+    batch in flight waits for it."""
+    from br_amd import _lib
+    from br_amd.correct import pack_reads
+    gs = br_amd.Pcon.from_pcon_solid(solid_fixture_bytes)
+    ref = O.Solid.from_bytes(solid_fixture_bytes)
+    methods = [("one", 5, 7), ("graph", 5, 7)]
+    om = O.build_methods(ref, ["one", "graph"], 5, 7)
+    batches = [raw_reads[i:i + 20] for i in range(0, 200, 20)]
+    packed = [pack_reads(b) for b in batches]
+    chains = [br_amd.Chain(gs, methods, two_side=False) for _ in range(3)]
+    got = [None] * len(batches)
+    for j, (bases, offs) in enumerate(packed):
+        ch = chains[j % 3]
+        if j >= 3:
+            got[j - 3] = ch.correct_batch_wait()
+        ch.correct_batch_async(bases, offs)
+    with pytest.raises(_lib.BrxError):
+        chains[(len(packed) - 1) % 3].correct_batch_async(*packed[0])     # busy
+    for j in range(len(packed) - 3, len(packed)):
+        got[j] = chains[j % 3].correct_batch_wait()
+    with pytest.raises(_lib.BrxError):
+        chains[0].correct_batch_wait()                                    # nothing in flight
+    sync = br_amd.Chain(gs, methods, two_side=False)
+    for b, (out, oo) in zip(batches, got):
+        reads = [out[int(oo[i]):int(oo[i + 1])].tobytes() for i in range(len(b))]
+        assert reads == sync.correct_reads(b)
+        assert reads == [O.correct_record(om, r, False) for r in b]
+    chains[1].correct_batch_async(*packed[0])
+    del chains                                                            # brx_chain_free joins the batch in flight
