@@ -23,6 +23,7 @@
 // (capacity = input length * (1 + slack/4) + 64); the reverse pass reads its input back to
 // front instead of materialising a reversed copy (src/lib.rs:111 reverses, does not complement).
 #include "brx_correct.hpp"
+#include <chrono>
 
 #include <stdlib.h>
 #include <string.h>
@@ -2353,19 +2354,25 @@ static int correct_batch_device_locked(brx_chain_t *ch, const uint8_t *d_bases, 
                 p.max_search = 0;
                 p.g_dim = 0;
                 p.g_lds_bytes = 0;
-                // BRX_LANE_REV (1 / 0; default: by index size): the REVERSE passes of Graph and GapSize in lane form too.
+                // BRX_LANE_REV (bit 0: Graph, bit 1: GapSize; default: by index size): REVERSE passes in lane form too.
                 // Their scan meets hardly a solid k-mer (the read is read back to front, not complemented), so over the
                 // solidity mask it is bit runs of sixteen positions a round -- but the rare trigger runs error_len to the
-                // END OF THE READ (hundreds of rounds of one lane, whose wave waits for it) and GapSize then walks thousands
-                // of fixed steps, which the lanes hand back.  Measured (profiles/r4c_*): at 2^25 index lines the lane form
-                // LOSES (graph 65.6 -> 75.4 ms per Gbp fwd+rev, gap_size 92 -> 211 with 1 845 reads redone by the list
-                // kernel); at 2^29 lines (the set every GPU of the 8-GPU jobs holds) it WINS: the 64-lane group kernels
-                // lose their L2-resident occupancy bits there and take ~180 ms per 8 Gbp pass, graph + gap_size
-                // 932 -> 748 ms.  So: on past 2^26 lines, off below.  One's reverse pass stays with its 64-lane kernel.
-                const bool lane_rev_default = idx.lines != nullptr && 32u - idx.line_shift > 26u;
+                // END OF THE READ (hundreds of rounds of one lane, whose wave waits for it), and GapSize then walks a gap
+                // of thousands of fixed steps along the genome (a deep-coverage set has long unbranched paths), which no
+                // unit's edit list holds: the lanes hand the read back.  Measured (profiles/r4c_*, r4e_*):
+                //   2^25 lines (configs[1]'s set)     graph 65.6 -> 75.4 ms per Gbp fwd+rev, gap_size 92 -> 211 (1 845 reads redone)
+                //   2^28 lines (configs[4]'s share)   graph + gap_size 714 -> 1 598 ms per step with both (770 ms of redo)
+                //   2^29 lines, 8x coverage, -a 1     graph + gap_size 932 -> 748 ms per 8 Gbp (walks die young in a set
+                //                                     with holes: nothing is handed back)
+                //   2^28 lines (configs[4]'s share)   Graph alone in lane form: 836 -> 877 ms per step (r4f)
+                // Only the last case gains (its 64-lane group kernels take ~180 ms per 8 Gbp pass at 2^29 lines), and a
+                // deep-coverage set of that size would hand reads back like the second.  So the form is OFF unless asked
+                // for; the switch stays for measurements and for the fuzzer, which sweeps it.
+                const unsigned lane_rev_default = 0u;
                 const char *e_rev = getenv("BRX_LANE_REV");
-                const bool lane_rev = e_rev && *e_rev ? *e_rev != '0' : lane_rev_default;
-                const bool lane_dir = dir == 0 ? !p.flip : (lane_rev && (mth == BRX_GRAPH || mth == BRX_GAP_SIZE));
+                const unsigned lane_rev = e_rev && *e_rev ? (unsigned)atoi(e_rev) : lane_rev_default;
+                const bool lane_dir = dir == 0 ? !p.flip
+                                               : ((mth == BRX_GRAPH && (lane_rev & 1u)) || (mth == BRX_GAP_SIZE && (lane_rev & 2u)));
                 if ((mth == BRX_ONE || mth == BRX_GRAPH || mth == BRX_GAP_SIZE) && lane_dir) {
                     // forward passes of One, Graph and GapSize (and the reverse ones of the latter two): one lane per chunk
                     // of a read (brx_onelane.hip) where that form applies
@@ -2515,6 +2522,12 @@ int brx_chain_correct_batch(brx_chain_t *ch, const uint8_t *bases, const uint64_
     *out_bases = nullptr;
     *out_offsets = nullptr;
     BRX_TRY(use_device(ch->device));
+    // BRX_TRACE=2: host wall time of the call's stages on stderr (where a batch from host memory spends its time)
+    static const bool tr_host = [] { const char *e = getenv("BRX_TRACE"); return e && *e == '2'; }();
+    const auto t_in = std::chrono::steady_clock::now();
+    auto ms_since = [&](std::chrono::steady_clock::time_point t0) {
+        return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    };
     // ONE lock from the upload to the download: the chain's own d_in / d_off / d_out staging is part of the workspace
     // a concurrent call on the same chain would overwrite (include/brx.h: "a chain serialises concurrent calls")
     std::lock_guard<std::mutex> g(ch->mu);
@@ -2550,6 +2563,7 @@ int brx_chain_correct_batch(brx_chain_t *ch, const uint8_t *bases, const uint64_
         BRX_TRY(ensure((void **)&ch->d_out_off, &cap_b, ((uint64_t)n_reads + 1) * 8));
         ch->d_out_off_cap = cap_b / 8;
     }
+    const double t_up = ms_since(t_in);
     uint64_t out_total = 0;
     uint64_t want = total + total / 16 + 4096;
     for (int attempt = 0; attempt < 3; attempt++) {
@@ -2564,6 +2578,7 @@ int brx_chain_correct_batch(brx_chain_t *ch, const uint8_t *bases, const uint64_
             return st;
         break;
     }
+    const double t_dev = ms_since(t_in);
     // the corrected batch comes back into pooled page-locked blocks (released by brx_buf_free like any other)
     uint8_t *hb = (uint8_t *)host_buf_acquire(out_total ? out_total : 1);
     uint64_t *ho = (uint64_t *)host_buf_acquire(((size_t)n_reads + 1) * 8);
@@ -2588,6 +2603,10 @@ int brx_chain_correct_batch(brx_chain_t *ch, const uint8_t *bases, const uint64_
     }
     *out_bases = hb;
     *out_offsets = ho;
+    if (tr_host)
+        fprintf(stderr, "[brx batch %p] %u reads %llu bases: upload %.2f ms, passes %.2f, download %.2f (at %.2f ms of the clock)\n", (void *)ch,
+                n_reads, (unsigned long long)total, t_up, t_dev - t_up, ms_since(t_in) - t_dev,
+                std::chrono::duration<double, std::milli>(t_in.time_since_epoch()).count());
     return BRX_OK;
 }
 

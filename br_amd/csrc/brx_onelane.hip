@@ -2163,7 +2163,9 @@ int lane_pass(brx_chain *ch, const PassParams &p, const LanePassInfo &info, hipS
     }
     {
         KernelTimer t("lane_apply", s);
-        const uint32_t grid = p.n_reads < (1u << 16) ? p.n_reads : (1u << 16);
+        // (BRX_AP_GRID: blocks of the replay kernels; each block loops over reads)
+        const uint32_t gcap = env_u32("BRX_AP_GRID", 1u << 20);
+        const uint32_t grid = p.n_reads < gcap ? p.n_reads : gcap;
         if (walk)
             lane_apply_walk_kernel<<<grid, 256, 0, s>>>(a);
         else

@@ -251,3 +251,39 @@ def test_two_chains_on_two_threads_share_a_fresh_successor_table(lane_env):
             assert chains[j].last_stats()["lane_units"] > 0
             bad = [i for i in range(len(reads)) if out[j][i] != want[m][i]]
             assert not bad, (rep, m, bad[:5])
+
+
+@pytest.mark.parametrize("rev", ["1", "2", "3"])
+def test_reverse_passes_in_lane_form(raw_reads, solid_fixture_bytes, lane_env, monkeypatch, rev):
+    """BRX_LANE_REV (bit 0 Graph, bit 1 GapSize): the reverse passes -- reads stored back to front, never copied
+    reversed (src/lib.rs:48-55) -- through the lane form as well: the packed copy and the replay read logical base j at
+    in[n - 1 - j].  Fixture reads (3 - 62 kb, k = 11: a dense set, so the reversed reads do meet solid k-mers, triggers
+    and walks) and synthetic ones at k = 19 against a counted set; chains whose second method sees staged, reversed
+    input; every read equals the oracle's and the group-kernel form's."""
+    lane_env(100, 2)
+    monkeypatch.setenv("BRX_LANE_REV", rev)
+    gs = br_amd.Pcon.from_pcon_solid(solid_fixture_bytes)
+    ref = O.Solid.from_bytes(solid_fixture_bytes)
+    reads = raw_reads[:40] + [b"", b"ACGTACGTAC", raw_reads[41][:11], raw_reads[42][:12], raw_reads[43][:27]]
+    for names in (["graph"], ["gap_size"], ["graph", "gap_size"], ["one", "gap_size", "graph"]):
+        chain = br_amd.Chain(gs, [(m, 5, 7) for m in names], two_side=False)
+        got = chain.correct_reads(reads)
+        assert chain.last_stats()["lane_unwritten_units"] == 0
+        om = O.build_methods(ref, names, 5, 7)
+        bad = [i for i, r in enumerate(reads) if got[i] != O.correct_record(om, r, False)]
+        assert not bad, (names, bad[:5])
+    k = 19
+    cfg = synth.config(genome_len=50_000, read_len=3_000)
+    g = synth.genome_host(cfg)
+    bases, offs = synth.reads_host(cfg, g, 0, 400)
+    sreads = [bases[int(offs[i]):int(offs[i + 1])].tobytes() for i in range(400)]
+    gs2 = br_amd.Pcon.from_count(sreads, k, 2)
+    ref2 = O.Solid.sparse_from_count(k, sreads, 2)
+    for names in (["graph"], ["gap_size"], ["gap_size", "graph"]):
+        got = br_amd.Chain(gs2, [(m, 5, 7) for m in names], two_side=False).correct_reads(sreads)
+        om = O.build_methods(ref2, names, 5, 7)
+        bad = [i for i, r in enumerate(sreads) if got[i] != O.correct_record(om, r, False)]
+        assert not bad, (names, bad[:5])
+        monkeypatch.setenv("BRX_LANE_REV", "0")
+        assert br_amd.Chain(gs2, [(m, 5, 7) for m in names], two_side=False).correct_reads(sreads) == got
+        monkeypatch.setenv("BRX_LANE_REV", rev)

@@ -170,8 +170,8 @@ while time.time() < t_end:
            "BRX_L1_GRID": str(rng.choice(["", "", "1", "5"])),
            # the solidity mask of the original k-mers: off / walking correctors (default) / One as well
            "BRX_LANE_MASK": str(rng.choice(["", "0", "2", "2"]))}
-    # reverse passes of Graph / GapSize in lane form (round 4): by index size (default: off at these sizes) / on / off
-    env["BRX_LANE_REV"] = str(xrng.choice(["", "1", "1", "0"]))
+    # reverse passes in lane form (round 4): by index size (default: off at these sizes) / Graph / GapSize / both / off
+    env["BRX_LANE_REV"] = str(xrng.choice(["", "1", "2", "3", "3", "0"]))
     if focus == "walklane":
         names[-1] = str(frng.choice(["graph", "gap_size"]))
         env.update({"BRX_LANE": "", "BRX_LANE_WALK": "", "BRX_LANE_CHUNK": str(frng.choice(["64", "100"])),
