@@ -358,6 +358,11 @@ def main():
         # host stages measured 3-8x slower on the same box (build 1.0 s instead of 0.16 s per Gbp)
         if not args.no_e2e and args.config == 1 and n_reads <= 200_000:
             host = host_8192(args, d_bases, d_off, n_reads, gs)
+            # the reference's batch size is a flag (`-b`, record_buffer_len, src/cli.rs): four times the records per call
+            # amortise what an 82 Mbp batch cannot -- the passes' fixed latency (profiles/r4f_host_batch_stages.txt)
+            host_big = host_8192(args, d_bases, d_off, n_reads, gs, per=32768, n_b=2)
+            if host is not None and host_big is not None:
+                host["records_32768"] = {k_: host_big.get(k_) for k_ in ("pinned", "pinned_async_3_chains", "error") if k_ in host_big}
             e2e = e2e_fasta(args, d_bases, d_off, n_reads, total, k, a)
         if not args.no_cpu_baseline:
             cpu = cpu_baseline(args, cfg, gs, k, n_reads, d_out, d_out_off)
@@ -545,7 +550,7 @@ def build_roofline(prof, total, steps, build_ms):
             "build_frac_survey_model": round(129 * total * steps / (build_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
 
 
-def host_8192(args, d_bases, d_off, n_reads, gs):
+def host_8192(args, d_bases, d_off, n_reads, gs, per=8192, n_b=4):
     """The boundary the reference would call: brx_chain_correct_batch on HOST buffers of 8192 records, the batch size
     of run_correction / populate_buffer (src/lib.rs:90,168-188) -- upload, both passes, download, per call.  Twice: the
     batches in ordinary (pageable) memory, and in brx_host_alloc (page-locked) blocks.  PCIe-inclusive: never `value`."""
@@ -554,7 +559,6 @@ def host_8192(args, d_bases, d_off, n_reads, gs):
     import br_amd
     from br_amd import _lib
     L = _lib.lib()
-    per, n_b = 8192, 4
     if n_reads < per * (n_b + 1):
         return None
     try:

@@ -125,7 +125,7 @@ KernelTimer::~KernelTimer()
 // A copy between HBM and PAGEABLE host memory goes through the runtime's own bounce buffers at 6-10 GB/s: 82 MB each
 // way per 8192-record batch was 2/3 of brx_chain_correct_batch's 31 ms (tools/host_rate.py, round 2).  Page-locked memory
 // moves at PCIe speed and asynchronously; hipHostMalloc itself costs milliseconds, so the blocks are pooled: a block
-// released by brx_buf_free / brx_host_free is kept (up to POOL_KEEP bytes) for the next batch.
+// released by brx_buf_free / brx_host_free is kept (up to BRX_HOSTPOOL_GB) for the next batch.
 namespace {
 struct HostBlock {
     void *p;
@@ -134,7 +134,18 @@ struct HostBlock {
 };
 std::mutex g_hostpool_mu;
 std::vector<HostBlock> g_hostpool;
-constexpr size_t POOL_KEEP = 1ull << 30;
+// idle page-locked bytes kept for reuse (BRX_HOSTPOOL_GB, default 4): three chains in flight with 32768-record batches
+// hold ~2 GiB of blocks between them -- at the first 1 GiB limit every batch paid a hipHostMalloc of its 328 MB output
+// again (67 ms per batch instead of 25: profiles/r4h_bench_n1.json records_32768 before the change)
+size_t pool_keep()
+{
+    static const size_t v = [] {
+        const char *e = getenv("BRX_HOSTPOOL_GB");
+        const double gb = e && *e ? atof(e) : 4.0;
+        return gb <= 0 ? (size_t)0 : (size_t)(gb * (double)(1ull << 30));
+    }();
+    return v;
+}
 }
 
 void *host_buf_acquire(size_t bytes)
@@ -180,7 +191,7 @@ void host_buf_release(void *p)
         }
         if (at < 0) { // not one of ours: it came from malloc
             drop = nullptr;
-        } else if (idle + g_hostpool[at].cap > POOL_KEEP) {
+        } else if (idle + g_hostpool[at].cap > pool_keep()) {
             drop = g_hostpool[at].p;
             g_hostpool.erase(g_hostpool.begin() + at);
             (void)hipHostFree(drop);

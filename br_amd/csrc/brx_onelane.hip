@@ -36,6 +36,8 @@
 #include "brx_correct.hpp"
 
 #include <stdlib.h>
+#include <algorithm>
+#include <vector>
 
 using namespace brx;
 
@@ -63,7 +65,22 @@ constexpr uint32_t AP_PIECES = 256; // pieces (unit, depth) gathered per batch
 constexpr uint32_t AP_BS = BRX_AP_BS; // threads of One's replay kernel per read
 constexpr uint32_t APW_EDITS = 512; // ... by the walking correctors' replay kernel
 constexpr uint32_t AP_VERIFY = 1024; // longest fixed-length walk whose k-mers the replay kernel checks for a repeat
-constexpr uint32_t LANE_GRAB = 64;           // units a wave draws from the global counter at a time
+constexpr uint32_t LANE_GRAB = 64;           // units a wave draws from the global counter at a time, at most
+// How many units a wave draws now.  A wave deals what it drew to its own lanes only, so what it still holds when the
+// counter runs dry is work no other wave can take: with 64 at a time the waves of configs[1]'s pass ended up to a whole
+// unit (~3 ms) apart.  Guided self-scheduling: draw 1 / (2 x waves) of what is left (as of this wave's last draw), 64 at
+// most, one at least -- the first half of the pass still costs one atomic per 64 units, only the last few per cent of
+// the units are fetched singly (one address takes ~125 M increments a second: 1.8 M units one by one were the whole
+// kernel's time, a few ten thousand are not).
+__device__ __forceinline__ uint32_t lane_grab(unsigned long long n_units, uint32_t last_base, uint32_t n_waves, uint32_t gss)
+{
+    if (!gss)
+        return LANE_GRAB;
+    const uint32_t left = (uint32_t)n_units - last_base; // (last_base <= n_units)
+    // (no division: the draw is 64 until less than 128 x waves units are left, then shrinks with a shift per halving)
+    const uint32_t per = 2u * n_waves;
+    return left >= LANE_GRAB * per ? LANE_GRAB : (left >= 16u * per ? 16u : (left >= 4u * per ? 4u : 1u));
+}
 #ifndef BRX_LANE_WAVES
 #define BRX_LANE_WAVES 7 // waves per SIMD the automaton is compiled for (tools/ab_build.sh sweeps it)
 #endif
@@ -72,6 +89,7 @@ struct UnitDesc;
 struct LaneArgs {
     PassParams p;
     uint32_t C;                // nominal chunk length
+    uint32_t r_half, r_quarter; // reads from r_half on are cut at C / 2, from r_quarter on at C / 4 (chunk_of)
     uint32_t R;                // solid original k-mers in a row that make a sync point
     uint32_t *nu;              // units per read                            [n_reads]
     uint64_t *ubase;           // exclusive scan of nu                      [n_reads + 1]
@@ -88,7 +106,19 @@ struct LaneArgs {
     uint32_t *BW[MAX_DEPTH];   // ... and the written bases, 16 per word, a fix starting a word
     uint32_t *fail_list;       // reads handed back to the group kernel     [n_reads]
     const uint64_t *succ;      // per index line, a byte per slot: the unique solid successor of either orientation (or null)
+    uint32_t gss;              // 1: the waves draw fewer units at a time as the pass runs out (lane_grab)
+    unsigned long long *dbg;   // BRX_LANE_TIMING: [0] waves recorded, then per wave: start, end (100 MHz ticks), loop iterations
 };
+
+// Chunk length of read r.  Units are handed out in read order and a lane keeps a unit to its end, so the pass ends
+// when the LAST units do: with 545-base units (~3 ms each at configs[1]) the waves of the automaton finished between
+// 10.3 and 15.8 ms (BRX_LANE_TIMING, profiles/r4h_lane_wave_timing.txt) -- the launch is as long as its slowest wave.
+// BRX_LANE_TAIL=1 cuts the reads at the end of the batch finer (what is dealt last is small); see lane_pass for what it gave.
+__device__ __forceinline__ uint32_t chunk_of(const LaneArgs &a, uint32_t r)
+{
+    const uint32_t c = r >= a.r_quarter ? a.C >> 2 : (r >= a.r_half ? a.C >> 1 : a.C);
+    return c < 64u ? 64u : c;
+}
 
 // byte offset of read r's input in its buffer, its length (0 for a poisoned read)
 __device__ __forceinline__ uint64_t read_view(const PassParams &p, uint32_t r, const uint8_t *&in, uint32_t &n, bool &poisoned)
@@ -144,7 +174,8 @@ __global__ __launch_bounds__(256) void lane_units_kernel(LaneArgs a)
     uint32_t n;
     bool poisoned;
     (void)read_view(a.p, r, in, n, poisoned);
-    a.nu[r] = n < 2u * a.C ? 1u : n / a.C; // the last unit takes the remainder
+    const uint32_t C = chunk_of(a, r);
+    a.nu[r] = n < 2u * C ? 1u : n / C; // the last unit takes the remainder
 }
 
 __global__ __launch_bounds__(256) void lane_pack_kernel(LaneArgs a)
@@ -231,8 +262,9 @@ __global__ __launch_bounds__(256) void lane_mask_kernel(LaneArgs a)
         const uint32_t j = ui.w, n = ui.z;
         const uint64_t at = ((uint64_t)ui.y << 32) | ui.x;
         const bool last = (uint64_t)j + 1ull == a.ubase[r + 1] - a.ubase[r];
-        const uint32_t s = (j * a.C) & ~15u; // (>= 64 for j >= 1: C >= 64)
-        const uint32_t lim = last ? n : ((j + 1u) * a.C) & ~15u;
+        const uint32_t C = chunk_of(a, r);
+        const uint32_t s = (j * C) & ~15u; // (>= 64 for j >= 1: C >= 64)
+        const uint32_t lim = last ? n : ((j + 1u) * C) & ~15u;
         const uint32_t *row = a.P + pack_start(at, r);
         uint16_t *mrow = a.M + pack_start(at, r);
         // the 31 bases in front of s: what the first k-mers of the stretch reach back into
@@ -301,8 +333,9 @@ __global__ __launch_bounds__(256) void lane_sync_kernel(LaneArgs a)
         const uint32_t r = mine ? a.u_read[u] : 0u;
         const uint64_t at = ((uint64_t)ui.y << 32) | ui.x;
         const uint32_t *row = a.P + pack_start(at, r);
-        const uint32_t s = j * a.C;
-        const uint32_t lim = (s + a.C < n) ? s + a.C : n; // k-mers ending at e < lim ...
+        const uint32_t C = chunk_of(a, r);
+        const uint32_t s = j * C;
+        const uint32_t lim = (s + C < n) ? s + C : n; // k-mers ending at e < lim ...
         const uint32_t e0 = s + k - 1u;                    // ... and starting at or behind s
         bool open_ = mine && j != 0u;                     // this half still looks for its unit's sync point
         uint32_t q = (mine && j == 0u) ? 0u : U_VOID;
@@ -370,8 +403,9 @@ __global__ __launch_bounds__(256) void lane_sync_mask_kernel(LaneArgs a)
         const uint64_t at = ((uint64_t)ui.y << 32) | ui.x;
         const uint32_t *row = a.P + pack_start(at, r);
         const uint16_t *mrow = a.M + pack_start(at, r);
-        const uint32_t s = j * a.C;
-        const uint32_t lim = (s + a.C < n) ? s + a.C : n; // k-mers ending at e < lim ...
+        const uint32_t C = chunk_of(a, r);
+        const uint32_t s = j * C;
+        const uint32_t lim = (s + C < n) ? s + C : n; // k-mers ending at e < lim ...
         const uint32_t e0 = s + k - 1u;                    // ... and starting at or behind s
         uint32_t q = U_VOID;
         uint64_t qk = 0;
@@ -419,7 +453,15 @@ struct __attribute__((aligned(16))) UnitDesc {
     uint64_t pw;    // dword of P that holds position q
     uint32_t ecap;  // entries up to the target's stretch
     uint32_t first; // 1: the read's first unit (the scan starts at position k, mod.rs:60-67)
+    // what used to be two more DEPENDENT trips of the lane that starts on the unit (a.u_qk[u], then the window at P[pw]):
+    // a unit starts 250 times per wave at configs[1] and the other 63 lanes wait for every trip
+    uint64_t qk;    // the original k-mer in front of q (a.u_qk[u]; unused for a read's first unit)
+    uint32_t m01;   // M[pw] | M[pw + 1] << 16 (0 without a mask)
+    uint32_t m2;    // M[pw + 2]
+    uint32_t w0, w1, w2; // P[pw], P[pw + 1], P[pw + 2]
+    uint32_t pad;
 };
+static_assert(sizeof(UnitDesc) == 80, "five 16-byte loads");
 
 __global__ __launch_bounds__(256) void lane_link_kernel(LaneArgs a)
 {
@@ -455,6 +497,13 @@ __global__ __launch_bounds__(256) void lane_link_kernel(LaneArgs a)
         d.ecap = (uint32_t)(end_at - d.eat);
         d.pw = pack_start(in_at, r) + (q0 >> 4);
         d.first = (uint32_t)u == ub ? 1u : 0u;
+        d.qk = d.first ? 0ull : a.u_qk[u];
+        d.w0 = a.P[d.pw];
+        d.w1 = a.P[d.pw + 1];
+        d.w2 = a.P[d.pw + 2];
+        d.m01 = a.M ? ((uint32_t)a.M[d.pw] | ((uint32_t)a.M[d.pw + 1] << 16)) : 0u;
+        d.m2 = a.M ? (uint32_t)a.M[d.pw + 2] : 0u;
+        d.pad = 0;
         a.u_desc[u] = d;
     }
 }
@@ -505,8 +554,16 @@ __global__ __launch_bounds__(256, MASK ? 6 : BRX_LANE_WAVES) void lane_kernel(La
     // a miss, makes fixes nobody keeps -- the replay kernel counts the ones it commits)
     uint32_t n_rounds = 0, n_probes = 0, n_trig = 0, n_miss = 0; // wave-uniform (scalar registers)
     uint32_t wnext = 0, wend = 0; // the units this wave has drawn and not yet dealt out (wave-uniform)
+    uint32_t wlast = 0; // where the global counter stood at this wave's last draw (units < 2^32)
+#ifdef BRX_LANE_TIMING // (a build of its own, -DBRX_LANE_TIMING: the counters cost the automaton its last free registers)
+    const unsigned long long t_begin = a.dbg ? wall_clock64() : 0ull;
+    uint32_t w_iters = 0;
+#endif
 
     for (;;) {
+#ifdef BRX_LANE_TIMING
+        w_iters++;
+#endif
         // ---- rare: a unit ends where the scan reaches its target (loop top, mod.rs:68); units are handed out --------
         uint32_t ev = 0; // this lane's events of the round: 1 probe, 2 trigger, 8 missed prediction, 16 a second probe
         const bool at_end = have && (S & 3u) == 0u && i >= tgt;
@@ -543,12 +600,14 @@ __global__ __launch_bounds__(256, MASK ? 6 : BRX_LANE_WAVES) void lane_kernel(La
                 if (!wm)
                     break;
                 if (wnext == wend) {
+                    const uint32_t grab = lane_grab(n_units, wlast, gridDim.x * 4u, a.gss);
                     unsigned long long base = 0;
                     if ((tid & 63u) == 0u)
-                        base = atomicAdd(p.ctrl + CTL_LANE_WORK, (unsigned long long)LANE_GRAB);
+                        base = atomicAdd(p.ctrl + CTL_LANE_WORK, (unsigned long long)grab);
                     base = __shfl(base, 0);
+                    wlast = base < n_units ? (uint32_t)base : (uint32_t)n_units;
                     wnext = base < n_units ? (uint32_t)base : (uint32_t)n_units;
-                    wend = base + LANE_GRAB < n_units ? (uint32_t)(base + LANE_GRAB) : (uint32_t)n_units;
+                    wend = base + grab < n_units ? (uint32_t)(base + grab) : (uint32_t)n_units;
                     if (wnext == wend) { // the pass has no units left
                         if (want)
                             have = false;
@@ -567,7 +626,7 @@ __global__ __launch_bounds__(256, MASK ? 6 : BRX_LANE_WAVES) void lane_kernel(La
                     have = true;
                     u = my;
                     const uint4 *dp = reinterpret_cast<const uint4 *>(a.u_desc + u);
-                    const uint4 d0 = dp[0], d1 = dp[1], d2 = dp[2];
+                    const uint4 d0 = dp[0], d1 = dp[1], d2 = dp[2], d3 = dp[3], d4 = dp[4]; // (one trip: everything to start on)
                     n = d0.x;
                     const uint32_t q = d0.y;
                     if (q >= U_VOID - 1u) {
@@ -585,13 +644,13 @@ __global__ __launch_bounds__(256, MASK ? 6 : BRX_LANE_WAVES) void lane_kernel(La
                         ne = 0;
                         hop = 0;
                         // the window at q
-                        wreg = (((uint64_t)a.P[pw] << 32) | a.P[pw + 1]) << ((q & 15u) * 2u);
+                        wreg = (((uint64_t)d4.x << 32) | d4.y) << ((q & 15u) * 2u);
                         wcnt = 32u - (q & 15u);
-                        nextw = a.P[pw + 2];
+                        nextw = d4.z;
                         pidx = (uint32_t)pw + 3u;
                         if (use_mask) {
-                            mw = ((uint32_t)a.M[pw] | ((uint32_t)a.M[pw + 1] << 16)) >> (q & 15u);
-                            nextm = a.M[pw + 2];
+                            mw = d3.z >> (q & 15u);
+                            nextm = d3.w;
                         }
                         if (d2.w) { // the read's first unit
                             if (n < (uint32_t)k) { // mod.rs:56-58: returned verbatim, i.e. no edits
@@ -611,7 +670,7 @@ __global__ __launch_bounds__(256, MASK ? 6 : BRX_LANE_WAVES) void lane_kernel(La
                             }
                         } else {
                             i = q;
-                            kmer = a.u_qk[u];
+                            kmer = ((uint64_t)d3.y << 32) | d3.x;
                             S = 1u << S_PREV; // R >= 1 solid k-mers end in front of q
                         }
                     }
@@ -823,6 +882,16 @@ __global__ __launch_bounds__(256, MASK ? 6 : BRX_LANE_WAVES) void lane_kernel(La
     }
     // statistics: one atomic per wave per counter
     if ((threadIdx.x & 63) == 0) {
+#ifdef BRX_LANE_TIMING
+        if (a.dbg) {
+            const unsigned long long at = atomicAdd(a.dbg, 1ull);
+            if (at < 16384ull) {
+                a.dbg[1 + 3 * at] = t_begin;
+                a.dbg[2 + 3 * at] = wall_clock64();
+                a.dbg[3 + 3 * at] = ((unsigned long long)n_rounds << 32) | w_iters;
+            }
+        }
+#endif
         if (n_rounds)
             atomicAdd(p.ctrl + CTL_ROUNDS, (unsigned long long)n_rounds);
         if (n_probes)
@@ -947,6 +1016,7 @@ __global__ __launch_bounds__(256, walk_waves(M)) void lane_walk_kernel(LaneArgs 
     uint32_t elen = 0, bpow = 1, blam = 0, np = 0, pacc = 0;
     uint32_t n_rounds = 0, n_probes = 0, n_trig = 0, n_miss = 0; // (fixes: counted by the replay kernel, as for One)
     uint32_t wnext = 0, wend = 0;
+    uint32_t wlast = 0;
 
     for (;;) {
         uint32_t ev = 0;
@@ -981,12 +1051,14 @@ __global__ __launch_bounds__(256, walk_waves(M)) void lane_walk_kernel(LaneArgs 
                 if (!wm)
                     break;
                 if (wnext == wend) {
+                    const uint32_t grab = lane_grab(n_units, wlast, gridDim.x * 4u, a.gss);
                     unsigned long long base = 0;
                     if ((tid & 63u) == 0u)
-                        base = atomicAdd(p.ctrl + CTL_LANE_WORK, (unsigned long long)LANE_GRAB);
+                        base = atomicAdd(p.ctrl + CTL_LANE_WORK, (unsigned long long)grab);
                     base = __shfl(base, 0);
+                    wlast = base < n_units ? (uint32_t)base : (uint32_t)n_units;
                     wnext = base < n_units ? (uint32_t)base : (uint32_t)n_units;
-                    wend = base + LANE_GRAB < n_units ? (uint32_t)(base + LANE_GRAB) : (uint32_t)n_units;
+                    wend = base + grab < n_units ? (uint32_t)(base + grab) : (uint32_t)n_units;
                     if (wnext == wend) {
                         if (want)
                             have = false;
@@ -1005,7 +1077,7 @@ __global__ __launch_bounds__(256, walk_waves(M)) void lane_walk_kernel(LaneArgs 
                     have = true;
                     u = my;
                     const uint4 *dp = reinterpret_cast<const uint4 *>(a.u_desc + u);
-                    const uint4 d0 = dp[0], d1 = dp[1], d2 = dp[2];
+                    const uint4 d0 = dp[0], d1 = dp[1], d2 = dp[2], d3 = dp[3], d4 = dp[4];
                     n = d0.x;
                     const uint32_t q = d0.y;
                     if (q >= U_VOID - 1u) {
@@ -1024,13 +1096,13 @@ __global__ __launch_bounds__(256, walk_waves(M)) void lane_walk_kernel(LaneArgs 
                         bw = 0;
                         hop = 0;
                         pbase = (uint32_t)pw - (q >> 4); // the read's first dword in P
-                        wreg = (((uint64_t)a.P[pw] << 32) | a.P[pw + 1]) << ((q & 15u) * 2u);
+                        wreg = (((uint64_t)d4.x << 32) | d4.y) << ((q & 15u) * 2u);
                         wcnt = 32u - (q & 15u);
-                        nextw = a.P[pw + 2];
+                        nextw = d4.z;
                         pidx = (uint32_t)pw + 3u;
                         if (use_mask) {
-                            mw = ((uint32_t)a.M[pw] | ((uint32_t)a.M[pw + 1] << 16)) >> (q & 15u);
-                            nextm = a.M[pw + 2];
+                            mw = d3.z >> (q & 15u);
+                            nextm = d3.w;
                         }
                         if (d2.w) {
                             if (n < (uint32_t)k) {
@@ -1050,7 +1122,7 @@ __global__ __launch_bounds__(256, walk_waves(M)) void lane_walk_kernel(LaneArgs 
                             }
                         } else {
                             i = q;
-                            kmer = a.u_qk[u];
+                            kmer = ((uint64_t)d3.y << 32) | d3.x;
                             S = 1u << W_PREV;
                         }
                     }
@@ -1990,7 +2062,16 @@ int lane_pass(brx_chain *ch, const PassParams &p, const LanePassInfo &info, hipS
         w = new LaneWork();
         ch->lane_ws = w;
     }
-    const uint64_t units_bound = info.in_total_bound / C + (uint64_t)p.n_reads + 1ull;
+    // BRX_LANE_TAIL=1: the last fifth of the batch's reads is cut at C / 2, the last twentieth at C / 4 (chunk_of).  OFF by
+    // default: measured at configs[1] (profiles/r4i_lane_tail_ab.txt) the pass got 0.9 ms SLOWER (2.35 M units instead of
+    // 1.8 M: every unit start stalls its wave, and the sync / replay kernels grow with the units), as did guided draws
+    // (BRX_LANE_GSS=1: no change) -- the thinning tail of the launch is not where its time goes.
+    // (One only: a walking corrector's fix has to fit its unit's list, and short units hand more reads back)
+    const bool graded = !walk && env_u32("BRX_LANE_TAIL", 0u) != 0u && p.n_reads >= 64u;
+    const uint32_t r_half = graded ? p.n_reads - p.n_reads / 5u : 0xffffffffu;
+    const uint32_t r_quarter = graded ? p.n_reads - p.n_reads / 20u : 0xffffffffu;
+    const uint32_t c_min = graded ? ((C >> 2) < 64u ? 64u : (C >> 2)) : C;
+    const uint64_t units_bound = info.in_total_bound / c_min + (uint64_t)p.n_reads + 1ull;
     if (units_bound >= 0xfffffff0ull)
         return BRX_ERR_UNSUPPORTED;
     const uint64_t p_bound = (info.in_total_bound >> 4) + 5ull * p.n_reads + 16ull;                        // dwords
@@ -2042,6 +2123,8 @@ int lane_pass(brx_chain *ch, const PassParams &p, const LanePassInfo &info, hipS
     LaneArgs a;
     a.p = p;
     a.C = C;
+    a.r_half = r_half;
+    a.r_quarter = r_quarter;
     a.R = R;
     a.nu = w->nu;
     a.ubase = w->ubase;
@@ -2070,6 +2153,16 @@ int lane_pass(brx_chain *ch, const PassParams &p, const LanePassInfo &info, hipS
         a.p.c = 1; // (unused by Graph; keeps the One branch's shifts in range)
     a.fail_list = w->fail_list;
     a.succ = nullptr;
+    a.gss = env_u32("BRX_LANE_GSS", 0u) != 0u ? 1u : 0u;
+    a.dbg = nullptr;
+    unsigned long long *d_dbg = nullptr;
+#ifdef BRX_LANE_TIMING
+    if (!walk && env_u32("BRX_LANE_TIMING", 0u) != 0u) { // (debug: when do the waves of the automaton start and end?)
+        BRX_HIP(hipMalloc((void **)&d_dbg, (1 + 3 * 16384) * 8));
+        BRX_HIP(hipMemsetAsync(d_dbg, 0, (1 + 3 * 16384) * 8, s));
+        a.dbg = d_dbg;
+    }
+#endif
     if (walk && idx && env_u32("BRX_LANE_SUCC", 1u) != 0u) {
         // the successor table of the set's index: built the first time a walking corrector runs on it, again when the
         // index has changed since
@@ -2159,6 +2252,30 @@ int lane_pass(brx_chain *ch, const PassParams &p, const LanePassInfo &info, hipS
                 launch_lane_walk<true, BRX_GAP_SIZE>(a, blocks, s);
             else
                 launch_lane_walk<false, BRX_GAP_SIZE>(a, blocks, s);
+        }
+    }
+    if (d_dbg) {
+        std::vector<unsigned long long> h(1 + 3 * 16384);
+        BRX_HIP(hipMemcpyAsync(h.data(), d_dbg, h.size() * 8, hipMemcpyDeviceToHost, s));
+        BRX_HIP(hipStreamSynchronize(s));
+        (void)hipFree(d_dbg);
+        const size_t nw = (size_t)(h[0] < 16384ull ? h[0] : 16384ull);
+        if (nw) {
+            std::vector<double> st(nw), en(nw), it(nw), lr(nw);
+            unsigned long long t0 = ~0ull;
+            for (size_t i = 0; i < nw; i++)
+                t0 = h[1 + 3 * i] < t0 ? h[1 + 3 * i] : t0;
+            for (size_t i = 0; i < nw; i++) {
+                st[i] = (double)(h[1 + 3 * i] - t0) * 0.01; // microseconds
+                en[i] = (double)(h[2 + 3 * i] - t0) * 0.01;
+                it[i] = (double)(h[3 + 3 * i] & 0xffffffffull);
+                lr[i] = (double)(h[3 + 3 * i] >> 32);
+            }
+            auto pct = [](std::vector<double> v, double q) { std::sort(v.begin(), v.end()); return v[(size_t)(q * (double)(v.size() - 1))]; };
+            fprintf(stderr, "[lane timing] %zu waves, %u reads; start us p0/p50/p100 %.0f/%.0f/%.0f; end us p0/p10/p50/p90/p99/p100 %.0f/%.0f/%.0f/%.0f/%.0f/%.0f; "
+                            "loop iterations per wave p0/p50/p100 %.0f/%.0f/%.0f; lane-rounds per wave p50/p100 %.0f/%.0f\n",
+                    nw, p.n_reads, pct(st, 0), pct(st, .5), pct(st, 1), pct(en, 0), pct(en, .1), pct(en, .5), pct(en, .9), pct(en, .99), pct(en, 1),
+                    pct(it, 0), pct(it, .5), pct(it, 1), pct(lr, .5), pct(lr, 1));
         }
     }
     {

@@ -10,6 +10,9 @@ import br_amd
 from br_amd import _lib, synth
 
 n_reads = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
+# METHOD_BENCH_BATCH=N: the set is built from all reads, the passes are timed on the first N only (what one
+# 8192-record host batch costs on the device against the full-size set)
+n_batch = int(os.environ.get("METHOD_BENCH_BATCH", "0")) or n_reads
 methods = sys.argv[2:] or ["one", "two", "graph", "gap_size", "greedy"]
 k, a, read_len = 19, 3, 10000
 cfg = synth.config(genome_len=n_reads * read_len // 50, read_len=read_len)
@@ -26,12 +29,15 @@ gs = cnt.finish(a, stream)
 del cnt
 d_out = torch.empty(int(total * 1.1) + (1 << 20), dtype=torch.uint8, device="cuda")
 d_oo = torch.empty(n_reads + 1, dtype=torch.int64, device="cuda")
+if n_batch < n_reads:
+    total = int(do[n_batch].item())
+    n_reads = n_batch
 _lib.profile_enable(True)
 rows = []
 for m in methods:
     chain = br_amd.Chain(gs, [(m, 5, 7)], two_side=False)
     best = None
-    for rep in range(2):
+    for rep in range(int(os.environ.get("METHOD_BENCH_REPS", "2"))):
         _lib.profile_reset()
         t0 = time.perf_counter()
         out_total = chain.correct_batch_device(db.data_ptr(), do.data_ptr(), n_reads, total, d_out.data_ptr(), d_out.numel(),
