@@ -42,6 +42,60 @@ __global__ __launch_bounds__(256) void line_probe(const uint32_t *__restrict__ t
         *sink = acc;
 }
 
+// the same probes with WORK dependent integer instructions between them (the lane automaton issues ~330 vector
+// instructions per probe round): does the SHAPE of the requests -- one lane pulling its 64-byte line in four 16-byte
+// pieces, or four neighbouring lanes pulling a quarter each -- matter once the memory pipe shares the CU with real work?
+// COOP = 0: lane l pulls its own line in four 16-byte pieces (four wave instructions, 64 lines each);
+// COOP = 1: in instruction e lane l pulls quarter l & 3 of the line of "owner" 16 e + (l >> 2) (four wave instructions,
+//           16 lines each, the four lanes of a line side by side).  Either way a wave-round fetches 64 lines with 4
+//           instructions and 64 B per lane.
+template <int SHARE, int BYTES, int WORK>
+__global__ __launch_bounds__(256, 7) void line_probe_mix(const uint32_t *__restrict__ t, uint64_t nlines_mask, int iters, uint32_t *sink)
+{
+    constexpr bool COOP = SHARE == 4;
+    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t wave0 = tid & ~63ull;
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t acc = 0, w = (uint32_t)tid | 1u;
+    for (int it = 0; it < iters; it++) {
+        uint4 v[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const uint64_t owner = COOP ? wave0 + 16u * e + (lane >> 2) : tid;
+            const uint64_t line = mix64(owner * 1315423911ull + (uint64_t)it) & nlines_mask;
+            v[e] = ((const uint4 *)(t + line * 16))[COOP ? (lane & 3u) : (uint32_t)e];
+        }
+#pragma unroll
+        for (int j = 0; j < WORK; j++)
+            w = w * 0x9E3779B1u + (w >> 7); // (independent of the loads: issue work to overlap them)
+#pragma unroll
+        for (int e = 0; e < 4; e++)
+            acc ^= v[e].x ^ v[e].y ^ v[e].z ^ v[e].w;
+    }
+    if ((acc ^ w) == 0x12345u)
+        *sink = acc;
+}
+
+template <int SHARE, int BYTES, int WORK>
+static void run_mix(const uint32_t *d, uint64_t mask, int iters, uint32_t *sink, int blocks)
+{
+    hipEvent_t a, b;
+    CK(hipEventCreate(&a));
+    CK(hipEventCreate(&b));
+    line_probe_mix<SHARE, BYTES, WORK><<<blocks, 256>>>(d, mask, iters, sink);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(a));
+    line_probe_mix<SHARE, BYTES, WORK><<<blocks, 256>>>(d, mask, iters, sink);
+    CK(hipEventRecord(b));
+    CK(hipEventSynchronize(b));
+    float ms;
+    CK(hipEventElapsedTime(&ms, a, b));
+    const double probes = (double)blocks * 256 * iters;
+    printf("mix %s work=%-3d blocks=%-5d: %8.3f ms  %7.2f Gline/s  (%.1f G wave-instructions/s of work)\n",
+           SHARE == 4 ? "four lanes per line  " : "one lane per line    ", WORK, blocks, ms, probes / ms / 1e6, probes / 64.0 * 3.0 * WORK / ms / 1e6);
+    fflush(stdout);
+}
+
 template <int SHARE, int BYTES>
 static void run(const uint32_t *d, uint64_t mask, int iters, uint32_t *sink, int blocks)
 {
@@ -75,6 +129,17 @@ int main(int argc, char **argv)
     CK(hipMemset(d, 1, nlines * 64));
     printf("table %.1f MiB (%llu lines)\n", nlines * 64.0 / (1 << 20), (unsigned long long)nlines);
     const int blocks = 8192;
+    if (argc > 3) { // mixed with work only
+        run_mix<1, 64, 0>(d, nlines - 1, iters, sink, blocks);
+        run_mix<4, 16, 0>(d, nlines - 1, iters, sink, blocks);
+        run_mix<1, 64, 50>(d, nlines - 1, iters, sink, blocks);
+        run_mix<4, 16, 50>(d, nlines - 1, iters, sink, blocks);
+        run_mix<1, 64, 100>(d, nlines - 1, iters, sink, blocks);
+        run_mix<4, 16, 100>(d, nlines - 1, iters, sink, blocks);
+        run_mix<1, 64, 200>(d, nlines - 1, iters, sink, blocks);
+        run_mix<4, 16, 200>(d, nlines - 1, iters, sink, blocks);
+        return 0;
+    }
     run<1, 4>(d, nlines - 1, iters, sink, blocks);
     run<1, 16>(d, nlines - 1, iters, sink, blocks);
     run<1, 64>(d, nlines - 1, iters, sink, blocks);
