@@ -65,22 +65,10 @@ constexpr uint32_t AP_PIECES = 256; // pieces (unit, depth) gathered per batch
 constexpr uint32_t AP_BS = BRX_AP_BS; // threads of One's replay kernel per read
 constexpr uint32_t APW_EDITS = 512; // ... by the walking correctors' replay kernel
 constexpr uint32_t AP_VERIFY = 1024; // longest fixed-length walk whose k-mers the replay kernel checks for a repeat
-constexpr uint32_t LANE_GRAB = 64;           // units a wave draws from the global counter at a time, at most
-// How many units a wave draws now.  A wave deals what it drew to its own lanes only, so what it still holds when the
-// counter runs dry is work no other wave can take: with 64 at a time the waves of configs[1]'s pass ended up to a whole
-// unit (~3 ms) apart.  Guided self-scheduling: draw 1 / (2 x waves) of what is left (as of this wave's last draw), 64 at
-// most, one at least -- the first half of the pass still costs one atomic per 64 units, only the last few per cent of
-// the units are fetched singly (one address takes ~125 M increments a second: 1.8 M units one by one were the whole
-// kernel's time, a few ten thousand are not).
-__device__ __forceinline__ uint32_t lane_grab(unsigned long long n_units, uint32_t last_base, uint32_t n_waves, uint32_t gss)
-{
-    if (!gss)
-        return LANE_GRAB;
-    const uint32_t left = (uint32_t)n_units - last_base; // (last_base <= n_units)
-    // (no division: the draw is 64 until less than 128 x waves units are left, then shrinks with a shift per halving)
-    const uint32_t per = 2u * n_waves;
-    return left >= LANE_GRAB * per ? LANE_GRAB : (left >= 16u * per ? 16u : (left >= 4u * per ? 4u : 1u));
-}
+constexpr uint32_t LANE_GRAB = 64;           // units a wave draws from the global counter at a time
+// (Round 4 measured guided self-scheduling of the draws -- fewer units at a time as the pass runs out, so that no wave
+// sits on units another could take -- with finer units for the last reads of the batch: no change / 0.9 ms slower,
+// profiles/r4i_lane_tail_ab.txt.  The draws are a constant again; BRX_LANE_TAIL keeps the graded chunks for measurements.)
 #ifndef BRX_LANE_WAVES
 #define BRX_LANE_WAVES 7 // waves per SIMD the automaton is compiled for (tools/ab_build.sh sweeps it)
 #endif
@@ -106,7 +94,6 @@ struct LaneArgs {
     uint32_t *BW[MAX_DEPTH];   // ... and the written bases, 16 per word, a fix starting a word
     uint32_t *fail_list;       // reads handed back to the group kernel     [n_reads]
     const uint64_t *succ;      // per index line, a byte per slot: the unique solid successor of either orientation (or null)
-    uint32_t gss;              // 1: the waves draw fewer units at a time as the pass runs out (lane_grab)
     uint32_t prefetch;         // 1: a SCAN round starts the next position's index line on its way (lane_kernel)
     unsigned long long *dbg;   // BRX_LANE_TIMING: [0] waves recorded, then per wave: start, end (100 MHz ticks), loop iterations
 };
@@ -454,15 +441,11 @@ struct __attribute__((aligned(16))) UnitDesc {
     uint64_t pw;    // dword of P that holds position q
     uint32_t ecap;  // entries up to the target's stretch
     uint32_t first; // 1: the read's first unit (the scan starts at position k, mod.rs:60-67)
-    // what used to be two more DEPENDENT trips of the lane that starts on the unit (a.u_qk[u], then the window at P[pw]):
-    // a unit starts 250 times per wave at configs[1] and the other 63 lanes wait for every trip
-    uint64_t qk;    // the original k-mer in front of q (a.u_qk[u]; unused for a read's first unit)
-    uint32_t m01;   // M[pw] | M[pw + 1] << 16 (0 without a mask)
-    uint32_t m2;    // M[pw + 2]
-    uint32_t w0, w1, w2; // P[pw], P[pw + 1], P[pw + 2]
-    uint32_t pad;
 };
-static_assert(sizeof(UnitDesc) == 80, "five 16-byte loads");
+// (Round 4 tried an 80-byte record that also carried the window's three dwords, the mask words and the k-mer in front of
+// the sync point -- one trip to memory per unit start instead of three dependent ones: One's launch did not move (11.05
+// against 11.09 ms per pass) and the walking automata, at their register limit, spilled and lost 10 % (graph 65.6 ->
+// 75.5 ms per Gbp): profiles/r4z_methods_1gbp.jsonl against r4c_methods_1gbp_lane_rev_off.jsonl.  Taken out again.)
 
 __global__ __launch_bounds__(256) void lane_link_kernel(LaneArgs a)
 {
@@ -498,13 +481,6 @@ __global__ __launch_bounds__(256) void lane_link_kernel(LaneArgs a)
         d.ecap = (uint32_t)(end_at - d.eat);
         d.pw = pack_start(in_at, r) + (q0 >> 4);
         d.first = (uint32_t)u == ub ? 1u : 0u;
-        d.qk = d.first ? 0ull : a.u_qk[u];
-        d.w0 = a.P[d.pw];
-        d.w1 = a.P[d.pw + 1];
-        d.w2 = a.P[d.pw + 2];
-        d.m01 = a.M ? ((uint32_t)a.M[d.pw] | ((uint32_t)a.M[d.pw + 1] << 16)) : 0u;
-        d.m2 = a.M ? (uint32_t)a.M[d.pw + 2] : 0u;
-        d.pad = 0;
         a.u_desc[u] = d;
     }
 }
@@ -558,7 +534,6 @@ __global__ __launch_bounds__(256, MASK ? 6 : BRX_LANE_WAVES) void lane_kernel(La
     // a miss, makes fixes nobody keeps -- the replay kernel counts the ones it commits)
     uint32_t n_rounds = 0, n_probes = 0, n_trig = 0, n_miss = 0; // wave-uniform (scalar registers)
     uint32_t wnext = 0, wend = 0; // the units this wave has drawn and not yet dealt out (wave-uniform)
-    uint32_t wlast = 0; // where the global counter stood at this wave's last draw (units < 2^32)
 #ifdef BRX_LANE_TIMING // (a build of its own, -DBRX_LANE_TIMING: the counters cost the automaton its last free registers)
     const unsigned long long t_begin = a.dbg ? wall_clock64() : 0ull;
     uint32_t w_iters = 0;
@@ -604,14 +579,12 @@ __global__ __launch_bounds__(256, MASK ? 6 : BRX_LANE_WAVES) void lane_kernel(La
                 if (!wm)
                     break;
                 if (wnext == wend) {
-                    const uint32_t grab = lane_grab(n_units, wlast, gridDim.x * 4u, a.gss);
                     unsigned long long base = 0;
                     if ((tid & 63u) == 0u)
-                        base = atomicAdd(p.ctrl + CTL_LANE_WORK, (unsigned long long)grab);
+                        base = atomicAdd(p.ctrl + CTL_LANE_WORK, (unsigned long long)LANE_GRAB);
                     base = __shfl(base, 0);
-                    wlast = base < n_units ? (uint32_t)base : (uint32_t)n_units;
                     wnext = base < n_units ? (uint32_t)base : (uint32_t)n_units;
-                    wend = base + grab < n_units ? (uint32_t)(base + grab) : (uint32_t)n_units;
+                    wend = base + LANE_GRAB < n_units ? (uint32_t)(base + LANE_GRAB) : (uint32_t)n_units;
                     if (wnext == wend) { // the pass has no units left
                         if (want)
                             have = false;
@@ -630,7 +603,7 @@ __global__ __launch_bounds__(256, MASK ? 6 : BRX_LANE_WAVES) void lane_kernel(La
                     have = true;
                     u = my;
                     const uint4 *dp = reinterpret_cast<const uint4 *>(a.u_desc + u);
-                    const uint4 d0 = dp[0], d1 = dp[1], d2 = dp[2], d3 = dp[3], d4 = dp[4]; // (one trip: everything to start on)
+                    const uint4 d0 = dp[0], d1 = dp[1], d2 = dp[2];
                     n = d0.x;
                     const uint32_t q = d0.y;
                     if (q >= U_VOID - 1u) {
@@ -648,13 +621,13 @@ __global__ __launch_bounds__(256, MASK ? 6 : BRX_LANE_WAVES) void lane_kernel(La
                         ne = 0;
                         hop = 0;
                         // the window at q
-                        wreg = (((uint64_t)d4.x << 32) | d4.y) << ((q & 15u) * 2u);
+                        wreg = (((uint64_t)a.P[pw] << 32) | a.P[pw + 1]) << ((q & 15u) * 2u);
                         wcnt = 32u - (q & 15u);
-                        nextw = d4.z;
+                        nextw = a.P[pw + 2];
                         pidx = (uint32_t)pw + 3u;
                         if (use_mask) {
-                            mw = d3.z >> (q & 15u);
-                            nextm = d3.w;
+                            mw = ((uint32_t)a.M[pw] | ((uint32_t)a.M[pw + 1] << 16)) >> (q & 15u);
+                            nextm = a.M[pw + 2];
                         }
                         if (d2.w) { // the read's first unit
                             if (n < (uint32_t)k) { // mod.rs:56-58: returned verbatim, i.e. no edits
@@ -674,7 +647,7 @@ __global__ __launch_bounds__(256, MASK ? 6 : BRX_LANE_WAVES) void lane_kernel(La
                             }
                         } else {
                             i = q;
-                            kmer = ((uint64_t)d3.y << 32) | d3.x;
+                            kmer = a.u_qk[u];
                             S = 1u << S_PREV; // R >= 1 solid k-mers end in front of q
                         }
                     }
@@ -1030,7 +1003,6 @@ __global__ __launch_bounds__(256, walk_waves(M)) void lane_walk_kernel(LaneArgs 
     uint32_t elen = 0, bpow = 1, blam = 0, np = 0, pacc = 0;
     uint32_t n_rounds = 0, n_probes = 0, n_trig = 0, n_miss = 0; // (fixes: counted by the replay kernel, as for One)
     uint32_t wnext = 0, wend = 0;
-    uint32_t wlast = 0;
 
     for (;;) {
         uint32_t ev = 0;
@@ -1065,14 +1037,12 @@ __global__ __launch_bounds__(256, walk_waves(M)) void lane_walk_kernel(LaneArgs 
                 if (!wm)
                     break;
                 if (wnext == wend) {
-                    const uint32_t grab = lane_grab(n_units, wlast, gridDim.x * 4u, a.gss);
                     unsigned long long base = 0;
                     if ((tid & 63u) == 0u)
-                        base = atomicAdd(p.ctrl + CTL_LANE_WORK, (unsigned long long)grab);
+                        base = atomicAdd(p.ctrl + CTL_LANE_WORK, (unsigned long long)LANE_GRAB);
                     base = __shfl(base, 0);
-                    wlast = base < n_units ? (uint32_t)base : (uint32_t)n_units;
                     wnext = base < n_units ? (uint32_t)base : (uint32_t)n_units;
-                    wend = base + grab < n_units ? (uint32_t)(base + grab) : (uint32_t)n_units;
+                    wend = base + LANE_GRAB < n_units ? (uint32_t)(base + LANE_GRAB) : (uint32_t)n_units;
                     if (wnext == wend) {
                         if (want)
                             have = false;
@@ -1091,7 +1061,7 @@ __global__ __launch_bounds__(256, walk_waves(M)) void lane_walk_kernel(LaneArgs 
                     have = true;
                     u = my;
                     const uint4 *dp = reinterpret_cast<const uint4 *>(a.u_desc + u);
-                    const uint4 d0 = dp[0], d1 = dp[1], d2 = dp[2], d3 = dp[3], d4 = dp[4];
+                    const uint4 d0 = dp[0], d1 = dp[1], d2 = dp[2];
                     n = d0.x;
                     const uint32_t q = d0.y;
                     if (q >= U_VOID - 1u) {
@@ -1110,13 +1080,13 @@ __global__ __launch_bounds__(256, walk_waves(M)) void lane_walk_kernel(LaneArgs 
                         bw = 0;
                         hop = 0;
                         pbase = (uint32_t)pw - (q >> 4); // the read's first dword in P
-                        wreg = (((uint64_t)d4.x << 32) | d4.y) << ((q & 15u) * 2u);
+                        wreg = (((uint64_t)a.P[pw] << 32) | a.P[pw + 1]) << ((q & 15u) * 2u);
                         wcnt = 32u - (q & 15u);
-                        nextw = d4.z;
+                        nextw = a.P[pw + 2];
                         pidx = (uint32_t)pw + 3u;
                         if (use_mask) {
-                            mw = d3.z >> (q & 15u);
-                            nextm = d3.w;
+                            mw = ((uint32_t)a.M[pw] | ((uint32_t)a.M[pw + 1] << 16)) >> (q & 15u);
+                            nextm = a.M[pw + 2];
                         }
                         if (d2.w) {
                             if (n < (uint32_t)k) {
@@ -1136,7 +1106,7 @@ __global__ __launch_bounds__(256, walk_waves(M)) void lane_walk_kernel(LaneArgs 
                             }
                         } else {
                             i = q;
-                            kmer = ((uint64_t)d3.y << 32) | d3.x;
+                            kmer = a.u_qk[u];
                             S = 1u << W_PREV;
                         }
                     }
@@ -2079,7 +2049,7 @@ int lane_pass(brx_chain *ch, const PassParams &p, const LanePassInfo &info, hipS
     // BRX_LANE_TAIL=1: the last fifth of the batch's reads is cut at C / 2, the last twentieth at C / 4 (chunk_of).  OFF by
     // default: measured at configs[1] (profiles/r4i_lane_tail_ab.txt) the pass got 0.9 ms SLOWER (2.35 M units instead of
     // 1.8 M: every unit start stalls its wave, and the sync / replay kernels grow with the units), as did guided draws
-    // (BRX_LANE_GSS=1: no change) -- the thinning tail of the launch is not where its time goes.
+    // (no change) -- the thinning tail of the launch is not where its time goes.
     // (One only: a walking corrector's fix has to fit its unit's list, and short units hand more reads back)
     const bool graded = !walk && env_u32("BRX_LANE_TAIL", 0u) != 0u && p.n_reads >= 64u;
     const uint32_t r_half = graded ? p.n_reads - p.n_reads / 5u : 0xffffffffu;
@@ -2167,7 +2137,6 @@ int lane_pass(brx_chain *ch, const PassParams &p, const LanePassInfo &info, hipS
         a.p.c = 1; // (unused by Graph; keeps the One branch's shifts in range)
     a.fail_list = w->fail_list;
     a.succ = nullptr;
-    a.gss = env_u32("BRX_LANE_GSS", 0u) != 0u ? 1u : 0u;
     // (measured, profiles/r4k_lane_prefetch_ab.txt: the pass gets 0.3-1.0 ms SLOWER with it -- the extra requests cost more
     // than the shorter wait saves: off)
     a.prefetch = env_u32("BRX_LANE_PREFETCH", 0u) != 0u ? 1u : 0u;

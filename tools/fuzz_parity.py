@@ -174,7 +174,6 @@ while time.time() < t_end:
     env["BRX_LANE_REV"] = str(xrng.choice(["", "1", "2", "3", "3", "0"]))
     # graded chunk lengths at the end of a batch (One's lane form): on (default) / off
     env["BRX_LANE_TAIL"] = str(xrng.choice(["", "1", "1"]))
-    env["BRX_LANE_GSS"] = str(xrng.choice(["", "1"]))
     if focus == "walklane":
         names[-1] = str(frng.choice(["graph", "gap_size"]))
         env.update({"BRX_LANE": "", "BRX_LANE_WALK": "", "BRX_LANE_CHUNK": str(frng.choice(["64", "100"])),
