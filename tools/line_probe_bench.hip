@@ -76,6 +76,137 @@ __global__ __launch_bounds__(256, 7) void line_probe_mix(const uint32_t *__restr
         *sink = acc;
 }
 
+// The automaton's shape: ONE line per lane per round, ~WORK x 3 vector instructions that DEPEND on it before the next
+// address is known (DEPTH = 1), through LDS like lane_kernel (LDS-DMA, then read back).  DEPTH = 2: the line of the round
+// AFTER next is requested before this round's work starts (its address is known a round ahead: a second slot), LINE_B
+// bytes per line (64: four 16-byte pieces, 32: two) -- what a compact index with two slots per lane would do.
+template <int LINE_B, int DEPTH, int WORK>
+__global__ __launch_bounds__(256, 7) void line_chain(const uint32_t *__restrict__ t, uint64_t nlines_mask, int iters, uint32_t *sink)
+{
+    __shared__ uint4 lc[DEPTH][LINE_B / 16][256];
+    const uint32_t tid = threadIdx.x, wb = tid & ~63u;
+    uint64_t x = ((uint64_t)blockIdx.x * 256u + tid) * 0x9E3779B97F4A7C15ull + 1u;
+    uint32_t w = (uint32_t)x | 1u, acc = 0;
+    auto issue = [&](int slot, uint64_t line) {
+        const uint8_t *L = reinterpret_cast<const uint8_t *>(t + (line & nlines_mask) * 16ull);
+#pragma unroll
+        for (int e = 0; e < LINE_B / 16; e++)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(L + 16 * e),
+                                             (__attribute__((address_space(3))) void *)&lc[slot][e][wb], 16, 0, 0);
+    };
+    // the address sequence of a lane is a pure function of (lane, round): known one round ahead, like a scan's next line
+    auto addr = [&](int it) { return mix64(x + (uint64_t)it); };
+    if (DEPTH == 2)
+        issue(0, addr(0));
+    for (int it = 0; it < iters; it++) {
+        const int cur = DEPTH == 2 ? (it & 1) : 0;
+        if (DEPTH == 2)
+            issue(cur ^ 1, addr(it + 1));
+        else
+            issue(0, addr(it));
+        if (DEPTH == 2)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LINE_B / 16) : "memory"); // all but the youngest line's pieces
+        else
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        uint32_t v = 0;
+#pragma unroll
+        for (int e = 0; e < LINE_B / 16; e++) {
+            const uint4 q = lc[cur][e][tid];
+            v ^= q.x ^ q.y ^ q.z ^ q.w;
+        }
+        w ^= v;
+#pragma unroll
+        for (int j = 0; j < WORK; j++)
+            w = w * 0x9E3779B1u + (w >> 7); // (depends on the line: the round's work)
+        acc += w;
+    }
+    if (acc == 0x12345u)
+        *sink = acc;
+}
+
+// The same dependent rounds, every lane wanting a 64-byte line of its own, but FOUR NEIGHBOURING LANES pull a quarter each:
+// in instruction e lane l fetches quarter l & 3 of the line of owner 16 e + (l >> 2) (the owner's address comes by
+// ds_bpermute), so a wave instruction touches 16 lines as whole 64-byte requests instead of 64 lines as 16-byte pieces.
+// The LDS-DMA puts lane l's 16 bytes at base + 16 l: owner o's line lies contiguous at lc[o >> 4][4 (o & 15) .. + 3], and
+// the owner reads its quarters in an order rotated by its lane (bank conflicts between lanes 64 bytes apart otherwise).
+template <int WORK>
+__global__ __launch_bounds__(256, 7) void line_chain_coop(const uint32_t *__restrict__ t, uint64_t nlines_mask, int iters, uint32_t *sink)
+{
+    __shared__ uint4 lc[4][4][64]; // [wave of the block][instruction e][lane]
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+    uint64_t x = ((uint64_t)blockIdx.x * 256u + tid) * 0x9E3779B97F4A7C15ull + 1u;
+    uint32_t w = (uint32_t)x | 1u, acc = 0;
+    for (int it = 0; it < iters; it++) {
+        const uint64_t line = mix64(x + (uint64_t)it) & nlines_mask;
+        const uint32_t lo = (uint32_t)line, hi = (uint32_t)(line >> 32);
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const int owner = 16 * e + (int)(lane >> 2);
+            const uint64_t ol = ((uint64_t)(uint32_t)__shfl((int)hi, owner) << 32) | (uint32_t)__shfl((int)lo, owner);
+            const uint8_t *L = reinterpret_cast<const uint8_t *>(t + ol * 16ull) + 16u * (lane & 3u);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)L,
+                                             (__attribute__((address_space(3))) void *)&lc[wv][e][0], 16, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        uint32_t v = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint32_t qd = ((uint32_t)j + (lane >> 2)) & 3u;
+            const uint4 q = lc[wv][lane >> 4][4u * (lane & 15u) + qd];
+            v ^= q.x ^ q.y ^ q.z ^ q.w;
+        }
+        w ^= v;
+#pragma unroll
+        for (int j = 0; j < WORK; j++)
+            w = w * 0x9E3779B1u + (w >> 7);
+        acc += w;
+    }
+    if (acc == 0x12345u)
+        *sink = acc;
+}
+
+template <int WORK>
+static void run_chain_coop(const uint32_t *d, uint64_t mask, int iters, uint32_t *sink)
+{
+    const int blocks = 256 * 7;
+    hipEvent_t a, b;
+    CK(hipEventCreate(&a));
+    CK(hipEventCreate(&b));
+    line_chain_coop<WORK><<<blocks, 256>>>(d, mask, iters, sink);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(a));
+    line_chain_coop<WORK><<<blocks, 256>>>(d, mask, iters, sink);
+    CK(hipEventRecord(b));
+    CK(hipEventSynchronize(b));
+    float ms;
+    CK(hipEventElapsedTime(&ms, a, b));
+    const double probes = (double)blocks * 256 * iters;
+    printf("chain 64-byte lines, four lanes a line,  %3d x 3 dependent instructions a round: %8.3f ms  %6.2f Gline/s  %5.2f us a round\n", WORK, ms,
+           probes / ms / 1e6, ms * 1e3 / iters);
+    fflush(stdout);
+}
+
+template <int LINE_B, int DEPTH, int WORK>
+static void run_chain(const uint32_t *d, uint64_t mask, int iters, uint32_t *sink)
+{
+    const int blocks = 256 * 7; // the automaton's grid: seven waves per SIMD, every lane busy
+    hipEvent_t a, b;
+    CK(hipEventCreate(&a));
+    CK(hipEventCreate(&b));
+    line_chain<LINE_B, DEPTH, WORK><<<blocks, 256>>>(d, mask, iters, sink);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(a));
+    line_chain<LINE_B, DEPTH, WORK><<<blocks, 256>>>(d, mask, iters, sink);
+    CK(hipEventRecord(b));
+    CK(hipEventSynchronize(b));
+    float ms;
+    CK(hipEventElapsedTime(&ms, a, b));
+    const double probes = (double)blocks * 256 * iters;
+    printf("chain %2d-byte lines, %d in flight per lane, %3d x 3 dependent instructions a round: %8.3f ms  %6.2f Gline/s  %5.2f us a round\n", LINE_B, DEPTH,
+           WORK, ms, probes / ms / 1e6, ms * 1e3 / iters);
+    fflush(stdout);
+}
+
 template <int SHARE, int BYTES, int WORK>
 static void run_mix(const uint32_t *d, uint64_t mask, int iters, uint32_t *sink, int blocks)
 {
@@ -129,6 +260,20 @@ int main(int argc, char **argv)
     CK(hipMemset(d, 1, nlines * 64));
     printf("table %.1f MiB (%llu lines)\n", nlines * 64.0 / (1 << 20), (unsigned long long)nlines);
     const int blocks = 8192;
+    if (argc > 3 && argv[3][0] == 'c') { // the automaton's shape: dependent rounds
+        run_chain<64, 1, 0>(d, nlines - 1, iters * 4, sink);
+        run_chain<64, 1, 100>(d, nlines - 1, iters * 4, sink);
+        run_chain<32, 1, 100>(d, nlines - 1, iters * 4, sink);
+        run_chain<32, 2, 100>(d, nlines - 1, iters * 4, sink);
+        run_chain<64, 1, 60>(d, nlines - 1, iters * 4, sink);
+        run_chain<32, 1, 60>(d, nlines - 1, iters * 4, sink);
+        run_chain<32, 2, 60>(d, nlines - 1, iters * 4, sink);
+        run_chain<32, 2, 0>(d, nlines - 1, iters * 4, sink);
+        run_chain_coop<0>(d, nlines - 1, iters * 4, sink);
+        run_chain_coop<60>(d, nlines - 1, iters * 4, sink);
+        run_chain_coop<100>(d, nlines - 1, iters * 4, sink);
+        return 0;
+    }
     if (argc > 3) { // mixed with work only
         run_mix<1, 64, 0>(d, nlines - 1, iters, sink, blocks);
         run_mix<4, 16, 0>(d, nlines - 1, iters, sink, blocks);
