@@ -94,7 +94,6 @@ struct LaneArgs {
     uint32_t *BW[MAX_DEPTH];   // ... and the written bases, 16 per word, a fix starting a word
     uint32_t *fail_list;       // reads handed back to the group kernel     [n_reads]
     const uint64_t *succ;      // per index line, a byte per slot: the unique solid successor of either orientation (or null)
-    uint32_t prefetch;         // 1: a SCAN round starts the next position's index line on its way (lane_kernel)
     unsigned long long *dbg;   // BRX_LANE_TIMING: [0] waves recorded, then per wave: start, end (100 MHz ticks), loop iterations
 };
 
@@ -507,10 +506,13 @@ __global__ __launch_bounds__(256, MASK ? 6 : BRX_LANE_WAVES) void lane_kernel(La
     // the index line a lane probed last, kept in LDS (element e of lane t at [e][t]: conflict-free 16-byte accesses):
     // consecutive k-mers of a read share their minimizer for ~3 positions, and a line fetched per lane per round is what
     // made the first form of this kernel wait for the L2 fabric
+    // (Round 4 measured two other ways of getting the line: a one-round-ahead fetch of the NEXT position's line into a sink,
+    // and four neighbouring lanes pulling a quarter each of one lane's line -- 54 G lines/s against 38-45 in
+    // tools/line_probe_bench.hip's chain of dependent rounds where EVERY lane fetches EVERY round.  In this kernel, where
+    // about half the lanes fetch in a round, both lose: 11.2-11.5 against 10.6-10.9 ms per pass, and 28.2 (with the
+    // quarters read back in a turned order: spills) / 22.6 (without) / 22.0 (six waves) against 21.6 ms for both passes:
+    // profiles/r4k_lane_prefetch_ab.txt, profiles/r4l_lane_coop_fetch_ab.txt.)
     __shared__ uint4 lc[4][256];
-    // where the one-round-ahead fetches of the NEXT position's line land (4 bytes a lane, never read: the point is that
-    // the line is on its way up the cache hierarchy while this round finishes; see the SCAN round below)
-    __shared__ uint32_t pf_sink[256];
     const uint32_t tid = threadIdx.x;
 
     // the unit
@@ -730,16 +732,6 @@ __global__ __launch_bounds__(256, MASK ? 6 : BRX_LANE_WAVES) void lane_kernel(La
                                                          (__attribute__((address_space(3))) void *)&lc[e][wb], 16, 0, 0);
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     cline = line;
-                }
-                // SCAN whose NEXT position lives in another line: that line is what the next round will ask for (unless this
-                // one triggers), and it is known now -- home2 was worked out for the two-position test.  Start it on its way:
-                // a 4-byte LDS-DMA load into a sink nobody reads (no register to keep, nothing waits for it before the next
-                // round's own wait), so that the line's 64 bytes come from the L2 / the memory-side cache by then instead of
-                // from HBM.  BRX_LANE_PREFETCH=1 (a.prefetch) turns it on; it is off, see lane_pass.
-                if (a.prefetch && is0 && need && !slow && hop == 0u && !first && home2 != home) {
-                    const uint8_t *Ln = reinterpret_cast<const uint8_t *>(p.idx.lines + (uint64_t)home2 * 8ull);
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)Ln,
-                                                     (__attribute__((address_space(3))) void *)&pf_sink[tid & ~63u], 4, 0, 0);
                 }
                 if (need && slow) { // the home line overflowed at build time and does not hold the key: the bit vector knows
                     const uint64_t h = key - 1ull;
@@ -2137,9 +2129,6 @@ int lane_pass(brx_chain *ch, const PassParams &p, const LanePassInfo &info, hipS
         a.p.c = 1; // (unused by Graph; keeps the One branch's shifts in range)
     a.fail_list = w->fail_list;
     a.succ = nullptr;
-    // (measured, profiles/r4k_lane_prefetch_ab.txt: the pass gets 0.3-1.0 ms SLOWER with it -- the extra requests cost more
-    // than the shorter wait saves: off)
-    a.prefetch = env_u32("BRX_LANE_PREFETCH", 0u) != 0u ? 1u : 0u;
     a.dbg = nullptr;
     unsigned long long *d_dbg = nullptr;
 #ifdef BRX_LANE_TIMING
