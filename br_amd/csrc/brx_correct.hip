@@ -321,7 +321,22 @@ template <int G, int M, bool LIST = false>
 // One fits 80 VGPRs without spilling: 6 waves per SIMD instead of 5 (the kernel waits on memory 60 % of the
 // time, measured 8 % faster), and its 64-lane form (no group shuffles to keep) fits 72: 7 waves; the other methods
 // keep the compiler's own choice
-__global__ __launch_bounds__(256, (M == BRX_ONE ? (G == 64 ? 7 : 6) : (M == BRX_GAP_SIZE ? 5 : 1))) void correct_kernel(PassParams p)
+// Greedy: the compiler's own choice is 110 registers = 4 waves per SIMD; its LDS (the alignment table, ~2 KB a group)
+// allows 5.  Held to 96 registers (20 bytes of scratch) it runs 5: 79.7 -> 69.1 ms per Gbp fwd+rev on the same box
+// (profiles/r4m_greedy_ab.txt) -- a round of a group is a dependent trip to memory, and more groups hide it.
+#ifndef BRX_GREEDY_WAVES
+#define BRX_GREEDY_WAVES 5
+#endif
+// Two: the compiler's choice is 101 registers = 5 waves; held to 85 it runs 6: 65.2 -> 54.8 ms per Gbp fwd+rev (7 waves,
+// 72 registers: 64.2 -- spills).  Graph's group kernel (92 registers, 5 waves) does not move at 6: 50.95 / 51.56.
+#ifndef BRX_TWO_WAVES
+#define BRX_TWO_WAVES 6
+#endif
+#ifndef BRX_GRAPH_WAVES
+#define BRX_GRAPH_WAVES 1 // (92 registers = 5 waves)
+#endif
+__global__ __launch_bounds__(256, (M == BRX_ONE ? (G == 64 ? 7 : 6)
+                                                : (M == BRX_GAP_SIZE ? 5 : (M == BRX_GREEDY ? BRX_GREEDY_WAVES : (M == BRX_TWO ? BRX_TWO_WAVES : BRX_GRAPH_WAVES))))) void correct_kernel(PassParams p)
 {
     constexpr bool HAS_ERRLEN = (M == BRX_GRAPH || M == BRX_GAP_SIZE);
     constexpr bool HAS_ONE = (M == BRX_ONE || M == BRX_GAP_SIZE);
@@ -369,6 +384,10 @@ __global__ __launch_bounds__(256, (M == BRX_ONE ? (G == 64 ? 7 : 6) : (M == BRX_
     // greedy state: iteration, path length in bases, alignment offset
     uint32_t git = 0, gnl = 0, steps = 0;
     int goff = 0;
+    // ... and its viewed set (greedy.rs:136): <= max_search + 1 k-mers, kept one per lane of the group when it has that
+    // many lanes (a scan of the chain's list in memory was a dependent round trip per iteration)
+    uint64_t gvis = 0;
+    const bool greg = HAS_GREEDY && (uint32_t)p.max_search + 1u <= (uint32_t)G;
     // statistics
     // per-wave totals (wave-uniform, so they live in scalar registers instead of four VGPRs of a kernel that is at its
     // register limit): the lanes note their events of a round in `ev`, the end of the round ballots them
@@ -640,7 +659,10 @@ __global__ __launch_bounds__(256, (M == BRX_ONE ? (G == 64 ? 7 : 6) : (M == BRX_
                 do_probe = gl < 4; // follow_graph -> next_nucs, greedy.rs:91-102
                 pk = add_nuc(wk, (uint64_t)gl, mask);
             } else if (HAS_GREEDY && st == ST_GVALID) {
-                // check_next_kmers, greedy.rs:104-117
+                // check_next_kmers, greedy.rs:104-117 -- and, in the lanes behind its c probes, follow_graph of the NEXT
+                // iteration (next_nucs of the same k-mer, greedy.rs:91-102): an iteration of greedy's loop nearly always
+                // ends in "the look-ahead does not hold, go on", and then the four answers are already there -- one round
+                // per iteration instead of two (7 of the ~15 rounds of a trigger)
                 const uint32_t rem2 = n - i - git;
                 const uint32_t e = sub * G + (uint32_t)gl;
                 if (rem2 >= c && e < c) {
@@ -651,6 +673,9 @@ __global__ __launch_bounds__(256, (M == BRX_ONE ? (G == 64 ? 7 : 6) : (M == BRX_
                         for (uint32_t q = 0; q <= e; q++)
                             pk = add_nuc(pk, nuc2bit(ld(i + git + q)), mask);
                     }
+                    do_probe = true;
+                } else if (c + 4u <= (uint32_t)G && (uint32_t)gl >= c && (uint32_t)gl < c + 4u) {
+                    pk = add_nuc(wk, (uint64_t)((uint32_t)gl - c), mask);
                     do_probe = true;
                 }
             }
@@ -707,6 +732,48 @@ __global__ __launch_bounds__(256, (M == BRX_ONE ? (G == 64 ? 7 : 6) : (M == BRX_
             int apply_t = -1;    // Two scenario to apply
             bool apply_path = false;
             uint32_t path_offset = 0;
+            // Greedy: what follows the four answers `am` of next_nucs(wk) (greedy.rs:147-168, up to match_alignement)
+            auto greedy_after_follow = [&](uint32_t am) {
+                if (__popc(am) == 1) { // follow_graph succeeded: extend the path
+                    const uint64_t a = (uint64_t)(__ffs(am) - 1);
+                    if (gl == 0)
+                        gL.y[k - 1 + (int)gnl] = bit2nuc(a);
+                    gnl++;
+                    wk = add_nuc(wk, a, mask);
+                }
+                // greedy.rs:153-157 (a failed follow leaves kmer in the set -> None).  The viewed set holds at most
+                // max_search + 1 k-mers: one per lane of the group when it has that many (`greg`), else the chain's list
+                bool hit = false;
+                if (greg) {
+                    hit = (uint32_t)gl < npath && gvis == wk;
+                } else {
+                    for (uint32_t j = gl; j < npath; j += G)
+                        hit |= __hip_atomic_load(path + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == wk;
+                }
+                const uint64_t anyhit = (__ballot(hit) >> gshift) & GM;
+                const uint32_t rem = n - i;
+                if (anyhit || rem < git) { // greedy.rs:159-161
+                    fail = true;
+                } else if (!greg && npath >= p.maxpath) {
+                    path_overflow();
+                } else {
+                    if (greg) {
+                        if ((uint32_t)gl == npath)
+                            gvis = wk;
+                    } else if (gl == 0) {
+                        __hip_atomic_store(path + npath, (unsigned long long)wk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    if (gl == 0 && git >= 1u)
+                        gL.x[k - 1 + (int)git - 1] = ld(i + git - 1u);
+                    npath++;
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    // greedy.rs:163-168 returns Some iff match_alignement finds an offset AND check_next_kmers
+                    // holds.  Both are pure, so the cheap one goes first: the c look-ahead probes (GVALID), and the
+                    // (k+i)^2 alignment only for the few candidates that pass them.
+                    sub = 0;
+                    st = ST_GVALID;
+                }
+            };
             if (st == ST_INIT) {
                 if (n < (uint32_t)k) {
                     finish();
@@ -849,7 +916,10 @@ __global__ __launch_bounds__(256, (M == BRX_ONE ? (G == 64 ? 7 : 6) : (M == BRX_
                         }
                         if (gl == 0) {
                             gL.y[k - 1] = bit2nuc(corr & 3ull);
-                            __hip_atomic_store(path, (unsigned long long)corr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if (greg)
+                                gvis = corr;
+                            else
+                                __hip_atomic_store(path, (unsigned long long)corr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         }
                         gnl = 1;
                         npath = 1;
@@ -1003,37 +1073,7 @@ __global__ __launch_bounds__(256, (M == BRX_ONE ? (G == 64 ? 7 : 6) : (M == BRX_
                 else
                     fail = true;
             } else if (HAS_GREEDY && st == ST_GFOLLOW) {
-                const uint32_t am = (uint32_t)(gmask & 0xfull);
-                if (__popc(am) == 1) { // follow_graph succeeded: extend the path
-                    const uint64_t a = (uint64_t)(__ffs(am) - 1);
-                    if (gl == 0)
-                        gL.y[k - 1 + (int)gnl] = bit2nuc(a);
-                    gnl++;
-                    wk = add_nuc(wk, a, mask);
-                }
-                bool hit = false; // greedy.rs:153-157 (a failed follow leaves kmer in the set -> None)
-                for (uint32_t j = gl; j < npath; j += G)
-                    hit |= __hip_atomic_load(path + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == wk;
-                const uint64_t anyhit = (__ballot(hit) >> gshift) & GM;
-                const uint32_t rem = n - i;
-                if (anyhit || rem < git) { // greedy.rs:159-161
-                    fail = true;
-                } else if (npath >= p.maxpath) {
-                    path_overflow();
-                } else {
-                    if (gl == 0) {
-                        __hip_atomic_store(path + npath, (unsigned long long)wk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if (git >= 1u)
-                            gL.x[k - 1 + (int)git - 1] = ld(i + git - 1u);
-                    }
-                    npath++;
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                    // greedy.rs:163-168 returns Some iff match_alignement finds an offset AND check_next_kmers
-                    // holds.  Both are pure, so the cheap one goes first: the c look-ahead probes (GVALID), and the
-                    // (k+i)^2 alignment only for the few candidates that pass them.
-                    sub = 0;
-                    st = ST_GVALID;
-                }
+                greedy_after_follow((uint32_t)(gmask & 0xfull));
             } else if (HAS_GREEDY && st == ST_GVALID) {
                 const uint32_t rem2 = n - i - git;
                 bool ok = rem2 >= c, done = false;
@@ -1047,14 +1087,18 @@ __global__ __launch_bounds__(256, (M == BRX_ONE ? (G == 64 ? 7 : 6) : (M == BRX_
                 } else if (ok) {
                     done = true;
                 }
-                if (!ok) {
+                // the next iteration: its follow_graph was asked in this very round when the lanes allow (phase 1)
+                auto next_iteration = [&]() {
                     st = ST_GFOLLOW;
                     if (++git >= (uint32_t)p.max_search)
                         fail = true;
+                    else if (c + 4u <= (uint32_t)G)
+                        greedy_after_follow((uint32_t)(gmask >> c) & 0xfu);
+                };
+                if (!ok) {
+                    next_iteration();
                 } else if (done && !greedy_align<G>(gL, gl, k - 1 + (int)git, k - 1 + (int)gnl, k - 1, goff)) {
-                    st = ST_GFOLLOW; // the look-ahead held but no alignment offset: next iteration (greedy.rs:163)
-                    if (++git >= (uint32_t)p.max_search)
-                        fail = true;
+                    next_iteration(); // the look-ahead held but no alignment offset: next iteration (greedy.rs:163)
                 } else if (done) {
                     // greedy.rs:165-167: offset = (local_corr.len() as i64 + off) as usize, wrapping add
                     if (olen + gnl + 1u > cap) {
