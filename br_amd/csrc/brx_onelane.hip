@@ -57,8 +57,14 @@ constexpr uint32_t C_VOID = 0xfffffff2u;   // res[6]: nothing produced
 constexpr uint32_t U_UNWRITTEN = 0xffffffffu; // res[6] as lane_pass leaves it before the automaton: no lane has been here
 constexpr int MAX_DEPTH = 3;               // edit lists: own stretch + two stretches scanned after a miss
 constexpr uint32_t MAX_LANE_READ = 1u << 28; // positions are kept in 28 bits of an edit
-constexpr uint32_t AP_EDITS = 512;  // fixes replayed per batch
-constexpr uint32_t AP_PIECES = 256; // pieces (unit, depth) gathered per batch
+#ifndef BRX_AP_EDITS
+#define BRX_AP_EDITS 512
+#endif
+#ifndef BRX_AP_PIECES
+#define BRX_AP_PIECES 256
+#endif
+constexpr uint32_t AP_EDITS = BRX_AP_EDITS;   // fixes replayed per batch
+constexpr uint32_t AP_PIECES = BRX_AP_PIECES; // pieces (unit, depth) gathered per batch
 #ifndef BRX_AP_BS
 #define BRX_AP_BS 128
 #endif
@@ -963,7 +969,13 @@ enum { WS_SCAN = 0, WS_ALTS = 1, WS_SCEN = 2, WS_MORE = 3, WS_ERRLEN = 4, WS_WAL
 enum { WM_GRAPH = 0, WM_ONE = 1, WM_INSSUB = 2 };
 // waves per SIMD the walking automata are compiled for: Graph needs 89 registers, GapSize (its One branch and the exact
 // visited rule on top) more than the 102 of five waves
-constexpr int walk_waves(int) { return 5; }
+#ifndef BRX_WALK_WAVES_GRAPH
+#define BRX_WALK_WAVES_GRAPH 5
+#endif
+#ifndef BRX_WALK_WAVES_GAP
+#define BRX_WALK_WAVES_GAP 5
+#endif
+constexpr int walk_waves(int m) { return m == BRX_GRAPH ? BRX_WALK_WAVES_GRAPH : BRX_WALK_WAVES_GAP; }
 
 template <bool IDX, int KT, int M>
 __global__ __launch_bounds__(256, walk_waves(M)) void lane_walk_kernel(LaneArgs a)
