@@ -1276,7 +1276,10 @@ __device__ __forceinline__ uint32_t row_scan8(uint32_t code)
 }
 
 template <int G, int KT, bool LIST = false>
-__global__ __launch_bounds__(256, 7) void one_kernel(PassParams p)
+#ifndef BRX_ONE64_WAVES
+#define BRX_ONE64_WAVES 7 // (the 64-lane form, every One chain's reverse pass; tools/ab_build.sh sweeps it)
+#endif
+__global__ __launch_bounds__(256, (G == 64 ? BRX_ONE64_WAVES : 7)) void one_kernel(PassParams p)
 {
     static_assert(G == 4 || G == 8 || G == 16 || G == 64, "one_kernel: 4, 8, 16 or 64 lanes per read");
     const int lane0 = threadIdx.x & 63;

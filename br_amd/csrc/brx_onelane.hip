@@ -57,11 +57,13 @@ constexpr uint32_t C_VOID = 0xfffffff2u;   // res[6]: nothing produced
 constexpr uint32_t U_UNWRITTEN = 0xffffffffu; // res[6] as lane_pass leaves it before the automaton: no lane has been here
 constexpr int MAX_DEPTH = 3;               // edit lists: own stretch + two stretches scanned after a miss
 constexpr uint32_t MAX_LANE_READ = 1u << 28; // positions are kept in 28 bits of an edit
+// (a 10 kb read has ~250 fixes in ~19 units: batches of 256 fixes / 128 pieces take most reads in one go and leave the
+// replay kernel's LDS at 9.5 KB a block -- 512 / 256 measured 2.37 against 2.22 ms per pass, profiles/r4m_greedy_ab.txt)
 #ifndef BRX_AP_EDITS
-#define BRX_AP_EDITS 512
+#define BRX_AP_EDITS 256
 #endif
 #ifndef BRX_AP_PIECES
-#define BRX_AP_PIECES 256
+#define BRX_AP_PIECES 128
 #endif
 constexpr uint32_t AP_EDITS = BRX_AP_EDITS;   // fixes replayed per batch
 constexpr uint32_t AP_PIECES = BRX_AP_PIECES; // pieces (unit, depth) gathered per batch
