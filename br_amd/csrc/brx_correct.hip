@@ -376,6 +376,11 @@ __global__ __launch_bounds__(256, (M == BRX_ONE ? (G == 64 ? 7 : 6)
     bool was_unres = false, kept_sol = false; // per lane: its probe of that round was unanswered / its answer
     // error_len / walk state
     uint32_t elen = 0, ej = 0, npath = 0, gap = 0;
+    // Graph / GapSize: error_len (mod.rs:130-152) has probed the k-mers that end at i + 1 .. i + elen - 1 and found none
+    // solid.  When the trigger then FAILS, the scan goes on over exactly those k-mers (the read's base stays in the
+    // k-mer, mod.rs:91-96), so positions below skip_until are copied through without asking again.  In a reverse pass
+    // -- where a trigger is a chance hit and error_len runs to the end of the read -- that is the rest of the read.
+    uint32_t skip_until = 0;
     uint64_t fc = 0, ek = 0, wk = 0;
     // Brent cycle detector of the graph walk (see ST_WALK)
     uint64_t tort = 0;
@@ -434,6 +439,7 @@ __global__ __launch_bounds__(256, (M == BRX_ONE ? (G == 64 ? 7 : 6)
             kmer = 0;
             prev = false;
             steps = 0;
+            skip_until = 0;
             return;
         }
     };
@@ -489,8 +495,10 @@ __global__ __launch_bounds__(256, (M == BRX_ONE ? (G == 64 ? 7 : 6)
             while (have && st == ST_SCAN && !slow && n - i >= 65u && olen + 66u <= cap) {
                 const uint8_t c8 = ld(i + (uint32_t)lane);
                 const uint64_t km = lane_kmer64_dpp(kmer, (uint32_t)nuc2bit(c8), lane, mask);
-                bool s1, u1 = false;
-                if (p.idx.lines) {
+                bool s1 = false, u1 = false;
+                if (HAS_ERRLEN && i + (uint32_t)lane < skip_until) {
+                    // (known not solid: error_len asked about it behind the trigger that failed)
+                } else if (p.idx.lines) {
                     const int pr = p.idx.line_bits ? index_probe_filtered(p.idx, km, k) : index_probe(p.idx, km, k);
                     s1 = pr == 1;
                     u1 = pr == 2;
@@ -545,7 +553,7 @@ __global__ __launch_bounds__(256, (M == BRX_ONE ? (G == 64 ? 7 : 6)
                 const bool valid = pos < n;
                 ch = valid ? ld(pos) : (uint8_t)0;
                 pk = lane_kmer(kmer, nuc2bit(ch));
-                do_probe = valid;
+                do_probe = valid && !(HAS_ERRLEN && pos < skip_until);
             } else if (HAS_ERRLEN && st == ST_ERRLEN) {
                 // error_len, mod.rs:130-152: probe seq[i+1..] until the first solid k-mer
                 const uint32_t rem = n - i;
@@ -1139,6 +1147,8 @@ __global__ __launch_bounds__(256, (M == BRX_ONE ? (G == 64 ? 7 : 6)
                     if (gl == 0)
                         out[olen] = ch_t;
                     olen += 1;
+                    if (HAS_ERRLEN)
+                        skip_until = i + elen; // (see its declaration)
                     i += 1;
                     prev = false;
                     if (i >= n)
