@@ -270,23 +270,12 @@ def main():
     checks = {"solid_per_genome_base": round(solid_bits / genome_len, 3)}
     if world > 1:
         # Every rank must end with THE SAME set -- the one thing the exchange is for.  One all-gather of a fingerprint per
-        # rank: popcount plus two order-independent 64-bit folds of the set's members (wrapping sums of k and of k * k over
-        # the solid-hash list; over the bit vector's words, weighted by their index, when the build kept no list).  The
+        # rank: popcount plus two order-independent 64-bit folds of the set's members (wrapping sums of the hashes and of
+        # their squares, whatever holds the set on this rank: list, chained table of a sparse set, bit vector).  The
         # gather runs over the job's own backend, so the ranks that answer are also the count of ranks RCCL really joined.
-        kl = gs.keylist_device(stream)
-        if kl is not None and kl[1] > 0:
-            keys = brx_dist.device_view(kl[0], kl[1] * 8).view(torch.int64)
-            f1, f2, how = int(keys.sum().item()), int((keys * keys).sum().item()), "solid-hash list"
-        else:
-            ptr, nbytes = gs.device_bits()
-            words = brx_dist.device_view(ptr, nbytes).view(torch.int64)
-            f1 = int(words.sum().item())
-            f2 = 0
-            step_w = 1 << 24
-            for lo_w in range(0, words.numel(), step_w):  # (index weights in slices: no second 16 GiB tensor)
-                part = words[lo_w:lo_w + step_w]
-                f2 = (f2 + int((part * torch.arange(lo_w + 1, lo_w + 1 + part.numel(), device=part.device)).sum().item())) & ((1 << 64) - 1)
-            how = "bit vector words"
+        n_fp, f1, f2 = gs.fingerprint(stream)     # (brx_set_fingerprint: list, chained table or bit vector -- same numbers)
+        how = "brx_set_fingerprint"
+        assert n_fp == solid_bits, (n_fp, solid_bits)
         to_i64 = lambda v: v - (1 << 64) if v >= (1 << 63) else v
         mine = torch.tensor([to_i64(int(solid_bits)), to_i64(f1 & ((1 << 64) - 1)), to_i64(f2 & ((1 << 64) - 1))], dtype=torch.int64,
                             device="cpu" if args.rehearse_on_one_gpu else "cuda")

@@ -67,6 +67,7 @@ SIGNATURES = {
     "brx_set_index_build": (C.c_int, [_vp, C.c_int, C.c_int, _vp]),
     "brx_set_index_build_from_keys_device": (C.c_int, [_vp, _vp, C.c_uint64, C.c_int, C.c_int, _vp]),
     "brx_set_keylist_device": (C.c_int, [_vp, _pp, _u64p, _vp]),
+    "brx_set_fingerprint": (C.c_int, [_vp, _u64p, _vp]),
     "brx_set_index_drop": (C.c_int, [_vp]),
     "brx_set_index_info": (C.c_int, [_vp, _u64p]),
     "brx_set_get_batch_indexed": (C.c_int, [_vp, _vp, C.c_uint32, _vp, _u64p]),

@@ -469,6 +469,110 @@ int brx_set_keylist_device(const brx_set_t *set, void **d_keys, uint64_t *n, voi
     return BRX_OK;
 }
 
+// ---- fingerprint: the same three numbers for the same SET, whatever holds it ------------------------------------------
+namespace {
+__device__ __forceinline__ void fp_add(unsigned long long *out, unsigned long long n, unsigned long long s1, unsigned long long s2)
+{
+    // wave sums by DPP-free shuffles, then one atomic per wave and number
+    for (int o = 32; o > 0; o >>= 1) {
+        n += __shfl_down(n, o);
+        s1 += __shfl_down(s1, o);
+        s2 += __shfl_down(s2, o);
+    }
+    if ((threadIdx.x & 63) == 0 && n) {
+        atomicAdd(out + 0, n);
+        atomicAdd(out + 1, s1);
+        atomicAdd(out + 2, s2);
+    }
+}
+__global__ __launch_bounds__(256) void fp_list_kernel(const uint64_t *__restrict__ keys, const unsigned long long *__restrict__ n_dev, uint64_t cap,
+                                                      unsigned long long *out)
+{
+    const uint64_t n = *n_dev < cap ? *n_dev : cap;
+    unsigned long long c = 0, s1 = 0, s2 = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256u) {
+        const unsigned long long h = keys[i];
+        c++;
+        s1 += h;
+        s2 += h * h;
+    }
+    fp_add(out, c, s1, s2);
+}
+__global__ __launch_bounds__(256) void fp_table_kernel(const uint64_t *__restrict__ lines, uint64_t n_lines, unsigned long long *out)
+{
+    unsigned long long c = 0, s1 = 0, s2 = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; i < n_lines * 8ull; i += (uint64_t)gridDim.x * 256u) {
+        const unsigned long long v = (i & 7ull) == 7ull ? 0ull : lines[i]; // (slot 7 is the line's header)
+        if (v) {
+            const unsigned long long h = v - 1ull;
+            c++;
+            s1 += h;
+            s2 += h * h;
+        }
+    }
+    fp_add(out, c, s1, s2);
+}
+__global__ __launch_bounds__(256) void fp_bits_kernel(const uint32_t *__restrict__ bits, uint64_t nwords, unsigned long long *out)
+{
+    unsigned long long c = 0, s1 = 0, s2 = 0;
+    for (uint64_t w = (uint64_t)blockIdx.x * 256u + threadIdx.x; w < nwords; w += (uint64_t)gridDim.x * 256u) {
+        uint32_t x = bits[w];
+        while (x) {
+            const unsigned long long h = w * 32ull + (unsigned long long)(__ffs(x) - 1);
+            x &= x - 1u;
+            c++;
+            s1 += h;
+            s2 += h * h;
+        }
+    }
+    fp_add(out, c, s1, s2);
+}
+} // namespace
+
+int brx_set_fingerprint(const brx_set_t *set, uint64_t *out3, void *stream)
+{
+    if (!set || !out3)
+        return BRX_ERR_ARG;
+    BRX_TRY(use_device(set->device));
+    hipStream_t s = (hipStream_t)stream;
+    unsigned long long *d = nullptr;
+    BRX_HIP(hipMalloc((void **)&d, 24));
+    hipError_t e = hipMemsetAsync(d, 0, 24, s);
+    const char *what = "list";
+    if (e == hipSuccess) {
+        if (set->keylist_valid) { // (a truncated list is never left valid with a set that has nothing else)
+            fp_list_kernel<<<2048, 256, 0, s>>>(set->d_keylist, set->d_keylist_n, set->keylist_cap, d);
+        } else if (no_bits(set)) {
+            // no bit vector (sparse, or lazy and not written): the chained table is exact and holds every key once
+            if (!set->idx_valid || !set->d_lines) {
+                (void)hipFree(d);
+                set_error("fingerprint: the set has neither a bit vector, nor a key list, nor a table");
+                return BRX_ERR_UNSUPPORTED;
+            }
+            what = "table";
+            fp_table_kernel<<<4096, 256, 0, s>>>(set->d_lines, 1ull << set->idx_log_lines, d);
+        } else {
+            what = "bits";
+            fp_bits_kernel<<<4096, 256, 0, s>>>(set->d_bits, set->nwords, d);
+        }
+        e = hipGetLastError();
+    }
+    unsigned long long h[3] = {0, 0, 0};
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(h, d, 24, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess)
+        e = hipStreamSynchronize(s);
+    (void)hipFree(d);
+    if (e != hipSuccess) {
+        set_error("fingerprint (%s): %s", what, hipGetErrorString(e));
+        return BRX_ERR_HIP;
+    }
+    out3[0] = h[0];
+    out3[1] = h[1];
+    out3[2] = h[2];
+    return BRX_OK;
+}
+
 int brx_set_index_drop(brx_set_t *set)
 {
     if (!set)

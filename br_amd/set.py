@@ -203,6 +203,13 @@ class Pcon(KmerSet):
         _lib.check(_lib.lib().brx_set_keylist_device(self._h, C.byref(ptr), C.byref(n), stream))
         return (ptr.value, n.value) if ptr.value else None
 
+    def fingerprint(self, stream: Optional[int] = None) -> Tuple[int, int, int]:
+        """(members, sum of their hashes mod 2^64, sum of the squares mod 2^64): the same for the same set whatever holds
+        it -- what the ranks of a multi-GPU job compare after the exchange"""
+        out = (C.c_uint64 * 3)()
+        _lib.check(_lib.lib().brx_set_fingerprint(self._h, out, stream))
+        return int(out[0]), int(out[1]), int(out[2])
+
     def index_drop(self) -> None:
         _lib.check(_lib.lib().brx_set_index_drop(self._h))
 

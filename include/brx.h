@@ -139,6 +139,11 @@ int brx_set_index_drop(brx_set_t *set);
  * brx_set_count_finish[_into]); *d_keys == NULL when there is none.  Valid until the set is mutated.
  * Lets the multi-GPU exchange ship the solid k-mers of a rank's range without scanning the bit vector.  */
 int brx_set_keylist_device(const brx_set_t *set, void **d_keys, uint64_t *n, void *stream);
+/* Three numbers that depend on the SET alone, not on what holds it (bit vector, solid-hash list, chained table):
+ * out3[0] = members, out3[1] = sum of their hashes (canonical >> 1) mod 2^64, out3[2] = sum of the squares mod 2^64.
+ * What the ranks of a multi-GPU job compare after the exchange (bench.py `checks.set_agree`): the reference has one
+ * process and one set (src/main.rs:35-47); here every rank must end with the same one.                              */
+int brx_set_fingerprint(const brx_set_t *set, uint64_t *out3, void *stream);
 /* info8: [0] valid, [1] m, [2] log2_lines, [3] keys, [4] keys left to the bitset (overflow), [5] bytes,
  * [6] the correction entry points would use an index for this k, [7] a key list is attached          */
 int brx_set_index_info(const brx_set_t *set, uint64_t *info8);

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 import br_amd
-from br_amd import synth
+from br_amd import _lib, synth
 from oracle import oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -164,3 +164,45 @@ def test_lazy_bit_vector(raw_reads, monkeypatch):
     for r, g in zip(reads[:40], got):
         assert g == O.correct_record(om, r, False)
     assert gs.to_solid_bytes() == ref.to_bytes()
+
+
+def test_fingerprint_is_a_property_of_the_set(monkeypatch):
+    """brx_set_fingerprint (members, sum of hashes, sum of squares, mod 2^64) -- what the ranks of a multi-GPU job compare
+    after the exchange -- must not depend on what holds the set: the reference's bit vector (dense count), the solid-hash
+    list of a partitioned finish (bit vector lazy), the chained table of a sparse set, a table built from a handed-over
+    list (the exchange's last step: the set's own list is void then).  All equal the oracle's members."""
+    import torch
+    from br_amd import dist as bd
+    k, a = 15, 2
+    cfg = synth.config(genome_len=40_000, read_len=2_000)
+    g = synth.genome_host(cfg)
+    bases, offs = synth.reads_host(cfg, g, 0, 400)
+    reads = [bases[int(offs[i]):int(offs[i + 1])].tobytes() for i in range(400)]
+    ref = O.Solid.from_count(k, O.count_reads(k, reads), a)
+    members = np.flatnonzero(np.unpackbits(ref.bits().view(np.uint8), bitorder="little")).astype(np.uint64)
+    with np.errstate(over="ignore"):
+        want = (int(members.size), int(members.sum(dtype=np.uint64)), int((members * members).sum(dtype=np.uint64)))
+    assert want[0] == ref.popcount()
+
+    dense = br_amd.Counter(k, 0, _lib.COUNT_DENSE)
+    dense.add_reads(reads)
+    assert dense.finish(a).fingerprint() == want                                  # bit vector
+
+    part = br_amd.Counter(k, 0, _lib.COUNT_SORTED)
+    part.add_reads(reads)
+    lazy = part.finish(a)
+    assert lazy.bits_state() == 1 and lazy.fingerprint() == want                  # solid-hash list, bit vector unwritten
+
+    monkeypatch.setenv("BRX_FORCE_SPARSE", "1")
+    part.add_reads(reads)
+    sparse = part.finish(a)
+    monkeypatch.delenv("BRX_FORCE_SPARSE")
+    assert sparse.is_sparse() and sparse.fingerprint() == want                    # its list ...
+    kl = sparse.keylist_device()
+    keys = bd.device_view(kl[0], kl[1] * 8).view(torch.int64).clone()
+    part.add_reads(reads)
+    monkeypatch.setenv("BRX_FORCE_SPARSE", "1")
+    sp2 = part.finish(a)
+    monkeypatch.delenv("BRX_FORCE_SPARSE")
+    sp2.index_build_from_keys_device(keys.data_ptr(), keys.numel())               # ... and the chained table alone
+    assert sp2.keylist_device() is None and sp2.fingerprint() == want
