@@ -410,7 +410,10 @@ __device__ __forceinline__ void l1_for_each_hash(const uint32_t *__restrict__ pk
     }
 }
 
-__global__ __launch_bounds__(256) void l1_hist_kernel(L1Args a)
+#ifndef BRX_L1HIST_WAVES
+#define BRX_L1HIST_WAVES 1 // (1 = the compiler's choice: 76 registers, six waves; tools/ab_build.sh sweeps it)
+#endif
+__global__ __launch_bounds__(256, BRX_L1HIST_WAVES) void l1_hist_kernel(L1Args a)
 {
     extern __shared__ uint32_t lds[]; // hist[B]
     __shared__ uint32_t pk[PACK_WORDS];
@@ -618,7 +621,10 @@ __device__ __forceinline__ void block_scan_bins(uint32_t B, const uint32_t *cntv
 constexpr uint32_t L1_SECTOR = 8;                              // keys per 32-byte sector
 constexpr uint32_t L1_OWN = ((1u << MAX_DIGIT_BITS) + 255u) / 256u; // digits per lane: t, t + 256
 
-__global__ __launch_bounds__(256, 5) void l1_scatter_kernel(L1Args a)
+#ifndef BRX_L1SCAT_WAVES
+#define BRX_L1SCAT_WAVES 5
+#endif
+__global__ __launch_bounds__(256, BRX_L1SCAT_WAVES) void l1_scatter_kernel(L1Args a)
 {
     // LDS: stage_key[T] | gsm[B] (u64: sector index | keys carried << 32 | phantoms << 36) | cnt[B] | lofs[B] | lcur[B]
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
@@ -789,7 +795,10 @@ __device__ __forceinline__ uint32_t ln_load(const LnArgs &a, uint64_t parent, ui
 }
 
 template <int KPT>
-__global__ __launch_bounds__(256) void ln_hist_kernel(LnArgs a)
+#ifndef BRX_LNHIST_WAVES
+#define BRX_LNHIST_WAVES 1 // (72 registers, seven waves)
+#endif
+__global__ __launch_bounds__(256, BRX_LNHIST_WAVES) void ln_hist_kernel(LnArgs a)
 {
     extern __shared__ uint32_t lds[]; // hist[B]
     const uint32_t B = 1u << a.bits;

@@ -184,25 +184,28 @@ def test_fingerprint_is_a_property_of_the_set(monkeypatch):
         want = (int(members.size), int(members.sum(dtype=np.uint64)), int((members * members).sum(dtype=np.uint64)))
     assert want[0] == ref.popcount()
 
-    dense = br_amd.Counter(k, 0, _lib.COUNT_DENSE)
-    dense.add_reads(reads)
-    assert dense.finish(a).fingerprint() == want                                  # bit vector
+    def counted(strategy, sparse=False):
+        if sparse:
+            monkeypatch.setenv("BRX_FORCE_SPARSE", "1")
+        try:
+            c = br_amd.Counter(k, 0, strategy)
+            c.add_reads(reads)
+            return c.finish(a)
+        finally:
+            monkeypatch.delenv("BRX_FORCE_SPARSE", raising=False)
 
-    part = br_amd.Counter(k, 0, _lib.COUNT_SORTED)
-    part.add_reads(reads)
-    lazy = part.finish(a)
-    assert lazy.bits_state() == 1 and lazy.fingerprint() == want                  # solid-hash list, bit vector unwritten
-
-    monkeypatch.setenv("BRX_FORCE_SPARSE", "1")
-    part.add_reads(reads)
-    sparse = part.finish(a)
-    monkeypatch.delenv("BRX_FORCE_SPARSE")
-    assert sparse.is_sparse() and sparse.fingerprint() == want                    # its list ...
+    dense = counted(_lib.COUNT_DENSE)
+    assert dense.popcount() == want[0]
+    assert dense.fingerprint() == want, ("bit vector", dense.fingerprint(), want)
+    lazy = counted(_lib.COUNT_SORTED)
+    assert lazy.bits_state() == 1                                                  # solid-hash list, bit vector unwritten
+    assert lazy.fingerprint() == want, ("list", lazy.fingerprint(), want)
+    sparse = counted(_lib.COUNT_SORTED, sparse=True)
+    assert sparse.is_sparse()
+    assert sparse.fingerprint() == want, ("sparse list", sparse.fingerprint(), want)
     kl = sparse.keylist_device()
     keys = bd.device_view(kl[0], kl[1] * 8).view(torch.int64).clone()
-    part.add_reads(reads)
-    monkeypatch.setenv("BRX_FORCE_SPARSE", "1")
-    sp2 = part.finish(a)
-    monkeypatch.delenv("BRX_FORCE_SPARSE")
-    sp2.index_build_from_keys_device(keys.data_ptr(), keys.numel())               # ... and the chained table alone
-    assert sp2.keylist_device() is None and sp2.fingerprint() == want
+    sp2 = counted(_lib.COUNT_SORTED, sparse=True)
+    sp2.index_build_from_keys_device(keys.data_ptr(), keys.numel())               # the exchange's last step: a handed-over list
+    assert sp2.keylist_device() is None                                            # ... the chained table alone holds the set
+    assert sp2.fingerprint() == want, ("table", sp2.fingerprint(), want)
