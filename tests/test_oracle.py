@@ -248,3 +248,21 @@ def test_greedy_ignored_vectors_are_known_different(unit_vectors):
         assert not all(got), v["name"]          # known-different (were this to pass, un-ignore the vector)
         seen += 1
     assert seen == 3
+
+
+def test_round3_fuzz_case_3213_is_a_pure_copy_of_the_batch_s_first_read():
+    """The one mismatch round 3 left unexplained (fuzz seed 1, case 3213: two, two, graph at k = 19) named a read by its
+    bases only.  The fuzzer's generator is deterministic, so the job is rebuilt here without a GPU
+    (tools/fuzz_case_cpu.py) and the oracle run over it pass by pass: the read is read 0 of the batch and none of its six
+    passes has a single trigger -- the expected output is the input.  profiles/r4_case3213_audit.md rests on this."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_case_cpu.py"), "1", "3213", "CGGTTCGGCATTATCAGTCGCCC"],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "chain=['two', 'two', 'graph']" in out.stdout and "k=19" in out.stdout
+    assert "read 0: 893 bases, 0 triggers in all passes" in out.stdout
+    passes = [ln for ln in out.stdout.splitlines() if ln.strip().startswith("dir ")]
+    assert len(passes) == 6 and all("893 ->    893" in ln and "triggers    0" in ln for ln in passes)
