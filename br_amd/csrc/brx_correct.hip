@@ -519,6 +519,31 @@ __global__ __launch_bounds__(256, (M == BRX_ONE ? (G == 64 ? 7 : 6)
                 n_probes += 64u;
                 steps++;
             }
+            // error_len (mod.rs:130-152) in a loop of its own, too: a trigger of a REVERSE pass is a chance hit, and error_len
+            // then runs to the end of the read -- 64 k-mers a round, none of them solid -- through the general round's whole
+            // state dispatch (Graph's reverse pass spent 5.6 G vector instructions where One's spends 2.6 G).  Full blocks
+            // without a solid k-mer stay here; the block that ends the search (a hit, the end of the read, an overflowed
+            // index line) is left to the general code, which redoes its (pure) probes.
+            while (HAS_ERRLEN && have && st == ST_ERRLEN && !slow && n - i > ej + 1u + 64u) {
+                const uint8_t c8 = ld(i + ej + 1u + (uint32_t)lane);
+                const uint64_t km = lane_kmer64_dpp(ek, (uint32_t)nuc2bit(c8), lane, mask);
+                bool s1, u1 = false;
+                if (p.idx.lines) {
+                    const int pr = p.idx.line_bits ? index_probe_filtered(p.idx, km, k) : index_probe(p.idx, km, k);
+                    s1 = pr == 1;
+                    u1 = pr == 2;
+                } else {
+                    s1 = probe(p.bits, km, k);
+                }
+                if (__ballot(s1 | u1))
+                    break;
+                ek = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(km >> 32), 63) << 32) |
+                     (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)km, 63);
+                ej += 64u;
+                n_rounds += 1u;
+                n_probes += 64u;
+                steps++;
+            }
         }
         uint32_t ev = 0;
         bool do_probe = false;
@@ -1151,10 +1176,26 @@ __global__ __launch_bounds__(256, (M == BRX_ONE ? (G == 64 ? 7 : 6)
                         skip_until = i + elen; // (see its declaration)
                     i += 1;
                     prev = false;
-                    if (i >= n)
+                    if (i >= n) {
                         finish();
-                    else
+                    } else if (HAS_ERRLEN && skip_until >= n) {
+                        // error_len ran off the read: no k-mer behind the trigger is solid, so no later one can trigger
+                        // (`previous` stays false) and the scan copies the rest of the read through (mod.rs:99-102) -- here
+                        // in one go, every lane's loads independent, instead of 64 bases a dependent round.  This is how
+                        // nearly every read of a reverse pass ends.
+                        const uint32_t left = n - i;
+                        if (olen + left + 1u > cap) {
+                            overflow();
+                        } else {
+                            for (uint32_t j = (uint32_t)gl; j < left; j += (uint32_t)G)
+                                out[olen + j] = ld(i + j);
+                            olen += left;
+                            i = n;
+                            finish();
+                        }
+                    } else {
                         st = ST_SCAN;
+                    }
                 }
             } else if (apply_s >= 0) {
                 // mod.rs:75-89 with one.rs:65-71
