@@ -1006,7 +1006,17 @@ __global__ __launch_bounds__(256, (M == BRX_ONE ? (G == 64 ? 7 : 6)
                 } else {
                     const uint64_t nk = add_nuc(wk, (uint64_t)(__ffs(am) - 1), mask);
                     bool revisit;
-                    if (brent) {
+                    // GapSize's fixed-length walk (gap_size.rs:57-85): the walk is deterministic -- every k-mer is the unique
+                    // solid successor of the one before -- so two equal k-mers drag everything behind them along, and a repeat
+                    // ANYWHERE in the walk shows as "the LAST k-mer was seen before".  The viewed set is therefore asked once,
+                    // when the gap is walked, instead of at every step: a reverse pass's rare long walks (thousands of steps
+                    // along the genome) had saturated the filter below and scanned their own list at every step -- quadratic,
+                    // 3 us a step, a 9 ms tail on the launch.  (A walk the reference would have cut short at its first revisit
+                    // goes on here to the end of the gap or to its first branch: None either way.)
+                    const bool deferred = !brent && mode == MODE_INSSUB;
+                    if (deferred) {
+                        revisit = false;
+                    } else if (brent) {
                         blam++;
                         revisit = (nk == tort);
                         if (!revisit && blam == bpow) {
@@ -1056,8 +1066,17 @@ __global__ __launch_bounds__(256, (M == BRX_ONE ? (G == 64 ? 7 : 6)
                                 }
                             }
                         } else if (--gap == 0u) {
-                            apply_path = true;
-                            path_offset = npath; // gap_size.rs:87-88
+                            // the deferred viewed-set check: nk against every k-mer of the walk before it (the list holds
+                            // them all: a walk that outgrew it was stopped above)
+                            bool hit = false;
+                            for (uint32_t j = gl; j + 1u < npath; j += G)
+                                hit |= __hip_atomic_load(path + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nk;
+                            if (((__ballot(hit) >> gshift) & GM) != 0ull) {
+                                fail = true; // gap_size.rs:75-81
+                            } else {
+                                apply_path = true;
+                                path_offset = npath; // gap_size.rs:87-88
+                            }
                         }
                     }
                 }

@@ -35,7 +35,8 @@ if n_batch < n_reads:
 _lib.profile_enable(True)
 rows = []
 for m in methods:
-    chain = br_amd.Chain(gs, [(m, 5, 7)], two_side=False)
+    # METHOD_BENCH_FWD_ONLY=1: the forward pass alone (two_side): the difference to the default run is the reverse pass
+    chain = br_amd.Chain(gs, [(m, 5, 7)], two_side=os.environ.get("METHOD_BENCH_FWD_ONLY", "") == "1")
     best = None
     for rep in range(int(os.environ.get("METHOD_BENCH_REPS", "2"))):
         _lib.profile_reset()
