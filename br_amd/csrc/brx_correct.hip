@@ -317,7 +317,10 @@ __device__ __forceinline__ uint32_t scen_width(uint32_t sub, uint32_t c, int G, 
     return left < cap ? left : cap;
 }
 
-template <int G, int M, bool LIST = false>
+// SRC: where the work comes from -- 0 every read of the batch, 1 the reads of a list made on the device (p.only), 2 the
+// triggers a lean reverse pass left open (p.trig; see rev_scan_kernel): the group enters at alt_nucs, writes nothing, and
+// flags the read for a redo unless the method returns None
+template <int G, int M, int SRC = 0>
 // One fits 80 VGPRs without spilling: 6 waves per SIMD instead of 5 (the kernel waits on memory 60 % of the
 // time, measured 8 % faster), and its 64-lane form (no group shuffles to keep) fits 72: 7 waves; the other methods
 // keep the compiler's own choice
@@ -347,6 +350,7 @@ __global__ __launch_bounds__(256, (M == BRX_ONE ? (G == 64 ? 7 : 6)
     constexpr bool HAS_TWO = (M == BRX_TWO);
     constexpr bool HAS_GREEDY = (M == BRX_GREEDY);
     constexpr bool HAS_PATH = HAS_WALK || HAS_GREEDY;
+    constexpr bool LIST = SRC == 1, VERIFY = SRC == 2;
     extern __shared__ __attribute__((aligned(16))) uint8_t dyn_lds[];
 
     const int lane = threadIdx.x & 63;
@@ -409,12 +413,20 @@ __global__ __launch_bounds__(256, (M == BRX_ONE ? (G == 64 ? 7 : 6)
                 w = atomicAdd(p.ctrl + CTL_WORK, 1ull);
             w = __shfl(w, gshift);
             // LIST: the reads of a list made on the device (what the lane-per-chunk pass handed back)
-            if (w >= (LIST ? *p.only_n : (unsigned long long)p.n_reads)) {
+            unsigned long long n_work = (unsigned long long)p.n_reads;
+            if (LIST || VERIFY)
+                n_work = *p.only_n;
+            if (VERIFY && n_work > (unsigned long long)p.trig_cap)
+                n_work = p.trig_cap; // (triggers beyond the buffer were not recorded: their reads were handed back whole)
+            if (w >= n_work) {
                 have = false;
                 return;
             }
             have = true;
-            r = LIST ? p.only[w] : (uint32_t)w;
+            TrigRec tr = {0, 0, 0, 0, 0};
+            if (VERIFY)
+                tr = p.trig[w];
+            r = VERIFY ? tr.r : (LIST ? p.only[w] : (uint32_t)w);
             const uint64_t o0 = p.offsets[r], o1 = p.offsets[r + 1];
             if (p.in_staged) {
                 in = p.in + slot_of(o0, r, p.slack);
@@ -440,6 +452,29 @@ __global__ __launch_bounds__(256, (M == BRX_ONE ? (G == 64 ? 7 : 6)
             prev = false;
             steps = 0;
             skip_until = 0;
+            if (VERIFY) {
+                // enter where the scan's trigger branch and error_len would have left the group (mod.rs:73-75 with
+                // mod.rs:130-152 / gap_size.rs:97-108): the read is unchanged up to the trigger
+                i = tr.i;
+                olen = tr.i;
+                uint64_t km = 0;
+                for (int j = 0; j < k; j++)
+                    km = (km << 2) | nuc2bit(in[p.flip ? (n - 1u - (tr.i + 1u - (uint32_t)k + (uint32_t)j)) : (tr.i + 1u - (uint32_t)k + (uint32_t)j)]);
+                kmer = km;
+                ch_t = in[p.flip ? (n - 1u - tr.i) : tr.i];
+                elen = tr.elen;
+                fc = tr.fc;
+                if (HAS_TWO)
+                    mode = MODE_TWO;
+                else if (M == BRX_GRAPH)
+                    mode = MODE_GRAPH;
+                else if (M == BRX_GAP_SIZE) {
+                    mode = elen < (uint32_t)k ? MODE_GRAPH : (elen == (uint32_t)k ? MODE_ONE : MODE_INSSUB);
+                    gap = elen > (uint32_t)k ? elen - (uint32_t)k : 0u;
+                } else
+                    mode = MODE_ONE;
+                st = ST_ALTS;
+            }
             return;
         }
     };
@@ -448,7 +483,15 @@ __global__ __launch_bounds__(256, (M == BRX_ONE ? (G == 64 ? 7 : 6)
     // A read is finished (or given up) at ONE place, the end of the round: every call site of an inlined fetch() redefines
     // the whole group state and costs a block of register copies at the join (one_kernel: 7 000 -> 4 900 lines of ISA)
     int done = 0; // 0 no, 1 finished, 16 + the CTL_* counter of the reason the read was given up
-    auto end_read = [&](int how) { done = how; };
+    bool flag_read = false; // VERIFY: this trigger does not end in None (or outgrew a workspace): the read is redone
+    auto end_read = [&](int how) {
+        if (VERIFY && how != 1) {
+            flag_read = true;
+            done = 1;
+        } else {
+            done = how;
+        }
+    };
     auto finish = [&]() { end_read(1); };
     auto overflow = [&]() { end_read(16 + CTL_OVERFLOW); };
     auto nonterminating = [&]() { end_read(16 + CTL_NONTERM); };
@@ -543,6 +586,64 @@ __global__ __launch_bounds__(256, (M == BRX_ONE ? (G == 64 ? 7 : 6)
                 n_rounds += 1u;
                 n_probes += 64u;
                 steps++;
+            }
+        }
+        if (HAS_WALK) {
+            // Walk steps (graph.rs:61-82, gap_size.rs:57-85) in a loop of their own, too: four probes, one successor, the
+            // cycle detector's bookkeeping, the list -- a fifth of a general round's instructions.  A reverse pass's walks
+            // follow the genome for hundreds to thousands of steps (the k-mer in front of a chance trigger is a genome
+            // k-mer), each a dependent trip to memory, and the launch that verifies or redoes them lasts as long as the
+            // walkers' steps take.  A step that ends the walk (no unique successor, a revisit, the target, the last step
+            // of a fixed-length walk, a full list) changes nothing here and is left to the general round, which asks the
+            // same (pure) probes again.  Narrow groups: the loop runs while at least as many groups of the wave walk as do
+            // anything else, and for eight steps at most while any other group waits.
+            constexpr uint64_t LEADERS = G == 64 ? 1ull : (G == 32 ? 0x0000000100000001ull : (G == 16 ? 0x0001000100010001ull : (G == 8 ? 0x0101010101010101ull : 0x1111111111111111ull)));
+            for (uint32_t it = 0;; it++) {
+                const bool wfast = have && st == ST_WALK && !slow && (brent || mode == MODE_INSSUB);
+                const uint32_t nw = (uint32_t)__builtin_popcountll(__ballot(wfast) & LEADERS);
+                const uint32_t no = (uint32_t)__builtin_popcountll(__ballot(have && !wfast) & LEADERS);
+                if (nw == 0u || nw < no || (no != 0u && it >= 8u))
+                    break;
+                bool s1 = false, u1 = false;
+                if (wfast && gl < 4) {
+                    const uint64_t q = add_nuc(wk, (uint64_t)gl, mask); // next_nucs(kmer), mod.rs:118-128
+                    if (p.idx.lines) {
+                        const int pr = index_probe(p.idx, q, k);
+                        s1 = pr == 1;
+                        u1 = pr == 2;
+                    } else {
+                        s1 = probe(p.bits, q, k);
+                    }
+                }
+                if (__ballot(u1))
+                    break; // an overflowed index line: the general round and its re-run settle it
+                const uint32_t am = (uint32_t)((__ballot(s1) >> gshift) & 0xfull);
+                bool simple = wfast && __popc(am) == 1;
+                uint64_t nk = 0;
+                if (simple) {
+                    nk = add_nuc(wk, (uint64_t)(__ffs(am) - 1), mask);
+                    simple = !(brent && nk == tort) && !(!brent && npath >= p.maxpath) &&
+                             !(mode == MODE_GRAPH ? nk == fc : gap <= 1u) && steps < (1u << 24) + 64u * n;
+                }
+                if (simple) {
+                    if (brent && ++blam == bpow) {
+                        tort = nk;
+                        bpow *= 2u;
+                        blam = 0;
+                    }
+                    if (gl == 0 && npath < p.maxpath)
+                        __hip_atomic_store(path + npath, (unsigned long long)nk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (npath < 0xfffffff0u)
+                        npath++;
+                    wk = nk;
+                    if (mode != MODE_GRAPH)
+                        gap--;
+                    steps++;
+                }
+                n_rounds += nw;
+                n_probes += 4u * nw;
+                if (__ballot(wfast && !simple))
+                    break;
             }
         }
         uint32_t ev = 0;
@@ -1158,7 +1259,10 @@ __global__ __launch_bounds__(256, (M == BRX_ONE ? (G == 64 ? 7 : 6)
                     next_iteration(); // the look-ahead held but no alignment offset: next iteration (greedy.rs:163)
                 } else if (done) {
                     // greedy.rs:165-167: offset = (local_corr.len() as i64 + off) as usize, wrapping add
-                    if (olen + gnl + 1u > cap) {
+                    if (VERIFY) {
+                        flag_read = true;
+                        finish();
+                    } else if (olen + gnl + 1u > cap) {
                         overflow();
                     } else {
                         for (uint32_t j = gl; j < gnl; j += G)
@@ -1183,7 +1287,10 @@ __global__ __launch_bounds__(256, (M == BRX_ONE ? (G == 64 ? 7 : 6)
                 nonterminating();
             }
 
-            if (fail) {
+            if (VERIFY && (fail || apply_s >= 0 || apply_t >= 0 || apply_path)) {
+                flag_read |= !fail; // None is what the lean scan assumed
+                finish();
+            } else if (fail) {
                 // mod.rs:91-96
                 if (olen + 2u > cap) {
                     overflow();
@@ -1288,7 +1395,13 @@ __global__ __launch_bounds__(256, (M == BRX_ONE ? (G == 64 ? 7 : 6)
             }
         }
         if (done) {
-            if (gl == 0) {
+            if (VERIFY) {
+                if (flag_read && gl == 0 && atomicExch(p.redo_flag + r, 1u) == 0u) {
+                    p.redo_list[atomicAdd(p.ctrl + CTL_REV_HANDBACK, 1ull)] = r;
+                    atomicAdd(p.ctrl + CTL_REV_HANDBACK_SUM, 1ull);
+                }
+                flag_read = false;
+            } else if (gl == 0) {
                 p.out_lens[r] = done == 1 ? olen : 0xffffffffu;
                 if (done != 1)
                     atomicAdd(p.ctrl + (done - 16), 1ull);
@@ -1928,6 +2041,251 @@ __global__ __launch_bounds__(256, (G == 64 ? BRX_ONE64_WAVES : 7)) void one_kern
     flush();
 }
 
+// ======================================================================================================================
+// Reverse passes of Graph / GapSize, lean form.  run_correction's second direction (src/lib.rs:48-55) reads
+// the read back to front WITHOUT complementing it: hardly a k-mer is solid, a trigger (mod.rs:73) is a chance hit, and what
+// follows it is all but always one of
+//   error_len (mod.rs:130-152) runs off the read        -> Graph: None (the target is not solid, no walk can reach it);
+//                                                          GapSize with error_len < k: the same
+//   alt_nucs does not name exactly one alternative      -> None for every method (exist/mod.rs:123-126, graph.rs:51-55,
+//                                                          greedy.rs, gap_size.rs:47-50)
+//   one alternative (the k-mer in front of the trigger is a genome k-mer, the alternative its successor in the genome)
+//                                                       -> the method goes to work and returns None after all: the walk
+//                                                          follows the genome and never meets a target that lies in a
+//                                                          reversed read; the scenarios' look-aheads do not hold
+// i.e. the read leaves the pass as it came.  This kernel scans on that assumption -- scan, error_len, alt_nucs, one wave
+// per read, 64 k-mers a round, nothing of the methods' state -- and NOTES every trigger of the third kind (TrigRec).  A
+// second launch, correct_kernel<8 or 16, M, 2>, takes the notes as its work items: a narrow group enters the method at
+// alt_nucs with the state the scan would have had there, runs it, writes nothing, and flags the read unless the result
+// is None; flagged reads (336 of 100 000 in One's reverse pass over the bench's data) are then corrected from scratch by
+// the list form of the group kernel.  A read none of whose triggers is flagged is exactly the copy the reference makes:
+// by induction over its triggers, each was reached with the reference's state and returned None like the reference's.
+// What it saves is the group kernel's register file (5 waves per SIMD against 8 here) and the instructions of its state
+// dispatch around rounds that are nearly all "64 positions, nothing".
+// ======================================================================================================================
+#ifndef BRX_REV_WAVES
+#define BRX_REV_WAVES 8
+#endif
+template <int KT, int M>
+__global__ __launch_bounds__(256, BRX_REV_WAVES) void rev_scan_kernel(const PassParams pp, uint32_t *__restrict__ handback, uint32_t *__restrict__ redo_flag,
+                                                                          TrigRec *__restrict__ notes, uint32_t trig_cap)
+{
+    // (the fields the loop needs, by value: a lambda that captures the parameter block by reference makes the compiler
+    // keep a copy of all of it in scratch)
+    const IdxView idx = pp.idx;
+    const uint32_t *const bits = pp.bits;
+    unsigned long long *const ctrl = pp.ctrl;
+    const uint32_t n_reads = pp.n_reads, slack = pp.slack;
+    const uint64_t *const offsets = pp.offsets;
+    const uint8_t *const in_base = pp.in;
+    const uint32_t *const in_lens = pp.in_lens;
+    const bool in_staged = pp.in_staged != 0, flip = pp.flip != 0;
+    uint8_t *const out_base = pp.out;
+    uint32_t *const out_lens = pp.out_lens;
+    constexpr bool HAS_ERRLEN = (M == BRX_GRAPH || M == BRX_GAP_SIZE);
+    const int lane = threadIdx.x & 63;
+    const int k = KT ? KT : pp.k;
+    const uint64_t mask = kmask(k);
+    uint32_t n_rounds = 0, n_probes = 0, n_trig = 0;
+
+    // KmerSet::get.  An index line that overflowed at build time cannot say "absent" (one probe in a thousand, i.e. nearly
+    // every 10 kb read meets one): the lane asks the bit vector, or -- sparse sets, whose keys chain into the following
+    // lines -- the next lines of the chain, while its wave waits.
+    const uint32_t n_lines_m1 = idx.lines ? (0xffffffffu >> idx.line_shift) : 0u;
+    auto ask = [&](uint64_t km) -> bool {
+        if (!idx.lines)
+            return probe(bits, km, k);
+        int a = idx.line_bits ? index_probe_filtered(idx, km, k) : index_probe(idx, km, k);
+        if (a == 2) {
+            if (bits)
+                return probe(bits, km, k);
+            for (uint32_t hop = 1; a == 2 && hop <= n_lines_m1; hop++)
+                a = index_probe(idx, km, k, hop);
+        }
+        return a == 1;
+    };
+    auto last_of = [&](uint64_t km, uint32_t l) -> uint64_t {
+        return ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(km >> 32), (int)l) << 32) |
+               (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)km, (int)l);
+    };
+
+    for (;;) {
+        unsigned long long w = 0;
+        if (lane == 0)
+            w = atomicAdd(ctrl + CTL_WORK, 1ull);
+        // (lane 0's value into a scalar register: everything derived from it -- the read's pointers, its length, the
+        // loop state -- then lives in scalar registers, too)
+        const uint32_t r = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)w);
+        if (__builtin_amdgcn_readfirstlane((int)(uint32_t)(w >> 32)) != 0 || r >= n_reads)
+            break;
+        const uint64_t o0 = offsets[r], o1 = offsets[r + 1];
+        const uint8_t *in;
+        uint32_t n;
+        if (in_staged) {
+            in = in_base + slot_of(o0, r, slack);
+            n = in_lens[r];
+            if (n == 0xffffffffu) { // poisoned by an earlier pass of this attempt: stays poisoned
+                if (lane == 0)
+                    out_lens[r] = 0xffffffffu;
+                continue;
+            }
+        } else {
+            in = in_base + o0;
+            n = (uint32_t)(o1 - o0);
+        }
+        const uint64_t s0 = slot_of(o0, r, slack), s1 = slot_of(o1, (uint64_t)r + 1, slack);
+        uint8_t *out = out_base + s0;
+        const uint32_t cap = (uint32_t)(s1 - s0);
+        auto ld = [&](uint32_t j) -> uint8_t { return in[flip ? (n - 1u - j) : j]; };
+
+        if (n < (uint32_t)k) { // mod.rs:56-58
+            for (uint32_t j = (uint32_t)lane; j < n; j += 64u)
+                out[j] = ld(j);
+            if (lane == 0)
+                out_lens[r] = n;
+            continue;
+        }
+        bool hb = n + 1u > cap; // (the group kernel's slot check; it poisons the read)
+        uint64_t kmer = 0;
+        uint32_t i = (uint32_t)k, skip_until = 0, trig_read = 0;
+        bool prev = false;
+        if (!hb) {
+            for (int j = 0; j < k; j++)
+                kmer = (kmer << 2) | nuc2bit(ld((uint32_t)j));
+            if (lane < k)
+                out[lane] = ld((uint32_t)lane);
+            prev = ask(kmer); // mod.rs:67
+            n_rounds++;
+            n_probes++;
+        }
+        while (!hb && i < n) {
+            // ---- scan: 64 positions (mod.rs:68-104 while nothing triggers) -------------------------------------------
+            const uint32_t pos = i + (uint32_t)lane;
+            const bool valid = pos < n;
+            const uint8_t c8 = valid ? ld(pos) : (uint8_t)0;
+            const uint64_t km = lane_kmer64_dpp(kmer, (uint32_t)nuc2bit(c8), lane, mask);
+            // (positions below skip_until: error_len asked about them behind a trigger that failed -- not solid)
+            const bool asks = valid && !(HAS_ERRLEN && pos < skip_until);
+            const bool a1 = asks && ask(km);
+            n_rounds++;
+            n_probes += (uint32_t)__builtin_popcountll(__ballot(asks));
+            const uint32_t left = n - i;
+            const uint32_t cnt = left < 64u ? left : 64u;
+            const uint64_t vmask = cnt >= 64u ? ~0ull : ((1ull << cnt) - 1ull);
+            const uint64_t bs = __ballot(a1);
+            const uint64_t trig = ~bs & ((bs << 1) | (prev ? 1ull : 0ull)) & vmask; // mod.rs:73
+            if (!trig) {
+                if (valid)
+                    out[pos] = c8; // mod.rs:100 (nothing changes the read here: output position == input position)
+                kmer = last_of(km, cnt - 1u);
+                prev = (bs >> (cnt - 1u)) & 1ull; // mod.rs:99
+                i += cnt;
+                continue;
+            }
+            const uint32_t t = (uint32_t)__builtin_ctzll(trig);
+            if ((uint32_t)lane < t)
+                out[pos] = c8;
+            i += t;
+            kmer = last_of(km, t); // the k-mer that triggered; the read's base stays in it when the method fails (mod.rs:91-96)
+            trig_read++;
+            uint32_t elen = 0;
+            uint64_t fc = 0;
+            bool hit_end = false;
+            if (HAS_ERRLEN) {
+                // ---- error_len, mod.rs:130-152: the k-mers behind the trigger until the first solid one ---------------
+                uint64_t ek = kmer;
+                uint32_t ej = 0;
+                const uint32_t rem = n - i;
+                for (;;) {
+                    const uint32_t j = ej + 1u + (uint32_t)lane;
+                    const bool v2 = j < rem;
+                    const uint8_t c2 = v2 ? ld(i + j) : (uint8_t)0;
+                    const uint64_t km2 = lane_kmer64_dpp(ek, (uint32_t)nuc2bit(c2), lane, mask);
+                    const bool a2 = v2 && ask(km2);
+                    n_rounds++;
+                    n_probes += (uint32_t)__builtin_popcountll(__ballot(v2));
+                    const uint64_t sm = __ballot(a2);
+                    if (sm) {
+                        const uint32_t t2 = (uint32_t)__builtin_ctzll(sm);
+                        elen = ej + 1u + t2;
+                        fc = last_of(km2, t2);
+                        break;
+                    }
+                    if (rem <= ej + 1u + 64u) { // ran off the read: the last k-mer built is not solid
+                        const uint32_t nv = rem - (ej + 1u);
+                        elen = rem;
+                        fc = nv ? last_of(km2, nv - 1u) : ek;
+                        hit_end = true;
+                        break;
+                    }
+                    ek = last_of(km2, 63u);
+                    ej += 64u;
+                }
+            }
+            // Graph: a target that is not solid cannot be reached (every walk k-mer is solid, graph.rs:79); GapSize sends
+            // error_len < k the same way (gap_size.rs:97-108)
+            const bool none_already = HAS_ERRLEN && hit_end && (M == BRX_GRAPH || elen < (uint32_t)k);
+            if (!none_already) {
+                // ---- alt_nucs: the read's own base is the trigger k-mer, known not solid ----------------------------
+                const bool asks3 = lane < 4 && (uint64_t)lane != (kmer & 3ull);
+                const bool a3 = asks3 && ask(add_nuc(kmer >> 2, (uint64_t)(lane & 3), mask));
+                n_rounds++;
+                n_probes += 3u;
+                if (__builtin_popcountll(__ballot(a3)) == 1) {
+                    // A unique alternative: the method goes to work -- in a reverse pass all but always to return None
+                    // after all (a walk along the genome that never meets the target, scenarios that do not hold).  The
+                    // scan goes on as if it had; the group kernel's verify pass checks this trigger (SRC == 2).
+                    unsigned long long at = 0;
+                    if (lane == 0)
+                        at = atomicAdd(ctrl + CTL_REV_TRIGS, 1ull);
+                    const uint32_t at_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)at);
+                    if (__builtin_amdgcn_readfirstlane((int)(uint32_t)(at >> 32)) != 0 || at_lo >= trig_cap) {
+                        hb = true; // (no room to note it: the whole read goes to the group kernel)
+                        break;
+                    }
+                    if (lane == 0) {
+                        notes[at_lo] = TrigRec{r, i, elen, 0u, fc};
+                        atomicAdd(ctrl + CTL_REV_TRIGS_SUM, 1ull);
+                    }
+                }
+            }
+            // ---- None: mod.rs:91-96 ------------------------------------------------------------------------------------
+            if (lane == 0)
+                out[i] = ld(i);
+            if (HAS_ERRLEN)
+                skip_until = i + elen;
+            i += 1u;
+            prev = false;
+            if (HAS_ERRLEN && skip_until >= n) {
+                // no k-mer behind the trigger is solid: nothing triggers any more (`previous` stays false)
+                for (uint32_t j = i + (uint32_t)lane; j < n; j += 64u)
+                    out[j] = ld(j);
+                i = n;
+            }
+        }
+        if (lane == 0) {
+            if (hb) {
+                if (atomicExch(redo_flag + r, 1u) == 0u) {
+                    handback[atomicAdd(ctrl + CTL_REV_HANDBACK, 1ull)] = r;
+                    atomicAdd(ctrl + CTL_REV_HANDBACK_SUM, 1ull);
+                }
+            } else {
+                out_lens[r] = n;
+            }
+        }
+        if (!hb)
+            n_trig += trig_read; // (a read handed back counts its events in the group kernel)
+    }
+    if (lane == 0) {
+        if (n_rounds)
+            atomicAdd(ctrl + CTL_ROUNDS, (unsigned long long)n_rounds);
+        if (n_probes)
+            atomicAdd(ctrl + CTL_PROBES, (unsigned long long)n_probes);
+        if (n_trig)
+            atomicAdd(ctrl + CTL_TRIGGERS, (unsigned long long)n_trig);
+    }
+}
+
 // one workgroup per read (grid-stride): staged slot -> compact output, reversing if needed
 __global__ __launch_bounds__(256) void compact_kernel(const uint8_t *__restrict__ stage, const uint32_t *__restrict__ lens,
                                                       const uint64_t *__restrict__ offsets, uint32_t n_reads,
@@ -2072,9 +2430,9 @@ int launch_walk_list(const PassParams &p, int method, hipStream_t s)
     uint32_t bl = (uint32_t)(sized_groups / 32u); // 32 eight-lane groups per block (the chain sizes at least 32 lists)
     bl = bl < 1u ? 1u : (bl > 128u ? 128u : bl);
     if (method == BRX_GRAPH)
-        correct_kernel<8, BRX_GRAPH, true><<<bl, 256, 0, s>>>(p);
+        correct_kernel<8, BRX_GRAPH, 1><<<bl, 256, 0, s>>>(p);
     else
-        correct_kernel<8, BRX_GAP_SIZE, true><<<bl, 256, 0, s>>>(p);
+        correct_kernel<8, BRX_GAP_SIZE, 1><<<bl, 256, 0, s>>>(p);
     BRX_HIP(hipGetLastError());
     return BRX_OK;
 }
@@ -2112,6 +2470,18 @@ int launch_method(const PassParams &p, int G, uint32_t blocks, size_t lds, hipSt
                 launch_one<16>(p, blocks, s);
             else
                 launch_one<64>(p, blocks, s);
+            return BRX_OK;
+        }
+    }
+    if constexpr (M == BRX_GRAPH || M == BRX_GAP_SIZE) {
+        if (p.trig) {
+            // the triggers a lean reverse pass left open, one 8-lane group each (a walk step is four probes)
+            correct_kernel<8, M, 2><<<blocks, 256, lds, s>>>(p);
+            return BRX_OK;
+        }
+        if (p.only) {
+            // the reads whose trigger did not end in None: a reverse pass over them, 64 lanes a read as usual
+            correct_kernel<64, M, 1><<<blocks, 256, lds, s>>>(p);
             return BRX_OK;
         }
     }
@@ -2168,8 +2538,16 @@ int launch_pass(PassParams p, const brx_method_t &md, int G, hipStream_t s)
         }
         lds = (size_t)(256 / G) * p.g_lds_bytes;
     }
-    const uint32_t blocks = pass_blocks(p.n_reads, G, method == BRX_ONE);
-    KernelTimer t(names[method], s);
+    uint32_t blocks = pass_blocks(p.n_reads, G, method == BRX_ONE);
+    if (p.only || p.trig) {
+        // a list is a few reads and the grid loops over it (the open triggers are many: as many groups as the visited lists
+        // the chain has sized allow); stay inside those lists (see launch_walk_list)
+        const uint64_t sized_groups = (uint64_t)pass_blocks(p.n_reads, walk_group()) * (256u / (uint32_t)walk_group());
+        const uint32_t per_block = p.trig ? 32u : 4u; // (8-lane groups for the triggers, 64-lane groups for the reads)
+        blocks = (uint32_t)(sized_groups / per_block);
+        blocks = blocks < 1u ? 1u : (blocks > MAX_BLOCKS ? MAX_BLOCKS : blocks);
+    }
+    KernelTimer t(p.trig ? "rev_verify" : (p.only ? "rev_redo" : names[method]), s);
     switch (method) {
     case BRX_ONE: BRX_TRY(launch_method<BRX_ONE>(p, G, blocks, lds, s)); break;
     case BRX_TWO: BRX_TRY(launch_method<BRX_TWO>(p, G, blocks, lds, s)); break;
@@ -2180,6 +2558,66 @@ int launch_pass(PassParams p, const brx_method_t &md, int G, hipStream_t s)
     }
     BRX_HIP(hipGetLastError());
     return BRX_OK;
+}
+
+// BRX_REV_LEAN=0: reverse passes of Graph / GapSize through the 64-lane group kernel as before (A/B runs,
+// and the fuzzer sweeps it)
+bool rev_lean_on()
+{
+    const char *e = getenv("BRX_REV_LEAN");
+    return !(e && *e == '0');
+}
+
+template <int M>
+void launch_rev_scan(const PassParams &p, uint32_t *list, uint32_t *flag, TrigRec *trig, uint32_t trig_cap, uint32_t blocks, hipStream_t s)
+{
+    if (p.k == 19)
+        rev_scan_kernel<19, M><<<blocks, 256, 0, s>>>(p, list, flag, trig, trig_cap);
+    else if (p.k == 21)
+        rev_scan_kernel<21, M><<<blocks, 256, 0, s>>>(p, list, flag, trig, trig_cap);
+    else
+        rev_scan_kernel<0, M><<<blocks, 256, 0, s>>>(p, list, flag, trig, trig_cap);
+}
+
+// a reverse pass in lean form (rev_scan_kernel), then the group kernel over the reads it handed back
+int launch_rev_lean(brx_chain *ch, PassParams p, const brx_method_t &md, hipStream_t s)
+{
+    static const char *names[5] = {"correct_pass", "correct_pass_two", "correct_pass_graph", "correct_pass_greedy",
+                                   "correct_pass_gap_size"};
+    // room for four open triggers per read on average (the bench's data: 1.2); a scan that finds no room hands its read back
+    const uint64_t trig_cap64 = 4ull * p.n_reads + 4096ull;
+    const uint32_t trig_cap = trig_cap64 > 0x7fffffffull ? 0x7fffffffu : (uint32_t)trig_cap64;
+    BRX_TRY(ensure((void **)&ch->d_rev_list, &ch->rev_list_bytes, (uint64_t)p.n_reads * 4ull));
+    BRX_TRY(ensure((void **)&ch->d_rev_flag, &ch->rev_flag_bytes, (uint64_t)p.n_reads * 4ull));
+    BRX_TRY(ensure(&ch->d_rev_trig, &ch->rev_trig_bytes, (uint64_t)trig_cap * sizeof(TrigRec)));
+    BRX_HIP(hipMemsetAsync(p.ctrl + CTL_REV_HANDBACK, 0, 8, s));
+    BRX_HIP(hipMemsetAsync(p.ctrl + CTL_REV_TRIGS, 0, 8, s));
+    BRX_HIP(hipMemsetAsync(ch->d_rev_flag, 0, (uint64_t)p.n_reads * 4ull, s));
+    TrigRec *trig = (TrigRec *)ch->d_rev_trig;
+    {
+        const uint32_t blocks = pass_blocks(p.n_reads, 64);
+        KernelTimer t(names[md.method], s);
+        switch (md.method) {
+        case BRX_GRAPH: launch_rev_scan<BRX_GRAPH>(p, ch->d_rev_list, ch->d_rev_flag, trig, trig_cap, blocks, s); break;
+        case BRX_GAP_SIZE: launch_rev_scan<BRX_GAP_SIZE>(p, ch->d_rev_list, ch->d_rev_flag, trig, trig_cap, blocks, s); break;
+        default: set_error("launch_rev_lean: method %u", md.method); return BRX_ERR_ARG;
+        }
+        BRX_HIP(hipGetLastError());
+    }
+    // the open triggers, one narrow group each
+    PassParams v = p;
+    v.trig = trig;
+    v.trig_cap = trig_cap;
+    v.only_n = p.ctrl + CTL_REV_TRIGS;
+    v.redo_list = ch->d_rev_list;
+    v.redo_flag = ch->d_rev_flag;
+    BRX_HIP(hipMemsetAsync(p.ctrl + CTL_WORK, 0, 8, s));
+    BRX_TRY(launch_pass(v, md, 16, s));
+    // ... and the reads whose trigger did not end in None (or that found no room for a note), from scratch
+    p.only = ch->d_rev_list;
+    p.only_n = p.ctrl + CTL_REV_HANDBACK;
+    BRX_HIP(hipMemsetAsync(p.ctrl + CTL_WORK, 0, 8, s));
+    return launch_pass(p, md, 16, s);
 }
 
 } // namespace
@@ -2517,7 +2955,13 @@ static int correct_batch_device_locked(brx_chain_t *ch, const uint8_t *d_bases, 
                     // lanes busy there (BRX_GROUP_WALK, default below); Two and Greedy need 16 lanes for their stage-1 probes
                     gw = (mth == BRX_GRAPH || mth == BRX_GAP_SIZE) ? walk_group() : 16;
                 }
-                BRX_TRY(launch_pass(p, ch->methods[m], gw, s));
+                // (Two's and Greedy's reverse passes cost 4 ms per Gbp of their 55 / 69 in the group kernel: the lean form
+                // was measured for them, too, and bought nothing -- profiles/r4o_rev_lean_ab.txt)
+                const bool lean = dir == 1 && (mth == BRX_GRAPH || mth == BRX_GAP_SIZE) && gw == 64 && rev_lean_on();
+                if (lean)
+                    BRX_TRY(launch_rev_lean(ch, p, ch->methods[m], s));
+                else
+                    BRX_TRY(launch_pass(p, ch->methods[m], gw, s));
                 cur = ch->d_stage[pp];
                 cur_lens = ch->d_lens[pp];
                 cur_staged = 1;
@@ -2536,9 +2980,11 @@ static int correct_batch_device_locked(brx_chain_t *ch, const uint8_t *d_bases, 
         BRX_HIP(hipMemcpyAsync(ch->h_ctrl, ch->d_ctrl, CTL_N * 8, hipMemcpyDeviceToHost, s));
         BRX_HIP(hipStreamSynchronize(s));
         if (tr_attempts)
-            fprintf(stderr, "[brx correct] attempt %u done: slot overflows %llu, walk list overflows %llu, nonterminating %llu\n", attempt,
+            fprintf(stderr, "[brx correct] attempt %u done: slot overflows %llu, walk list overflows %llu, nonterminating %llu, "
+                            "lean reverse passes: %llu open triggers verified, %llu reads redone\n", attempt,
                     (unsigned long long)ch->h_ctrl[CTL_OVERFLOW], (unsigned long long)ch->h_ctrl[CTL_PATHOVF],
-                    (unsigned long long)ch->h_ctrl[CTL_NONTERM]);
+                    (unsigned long long)ch->h_ctrl[CTL_NONTERM], (unsigned long long)ch->h_ctrl[CTL_REV_TRIGS_SUM],
+                    (unsigned long long)ch->h_ctrl[CTL_REV_HANDBACK_SUM]);
         stats[4] = attempt;
         if (ch->h_ctrl[CTL_NONTERM] != 0) {
             set_error("%llu read(s): the scan does not terminate (e.g. greedy moving the read cursor backwards for ever; "
@@ -2834,6 +3280,12 @@ void brx_chain_free(brx_chain_t *ch)
             (void)hipFree(ch->d_ctrl);
         if (ch->d_path)
             (void)hipFree(ch->d_path);
+        if (ch->d_rev_list)
+            (void)hipFree(ch->d_rev_list);
+        if (ch->d_rev_flag)
+            (void)hipFree(ch->d_rev_flag);
+        if (ch->d_rev_trig)
+            (void)hipFree(ch->d_rev_trig);
         if (ch->h_ctrl)
             (void)hipHostFree(ch->h_ctrl);
         if (ch->d_in)

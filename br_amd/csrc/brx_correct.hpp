@@ -14,8 +14,22 @@ enum { CTL_WORK = 0, CTL_OVERFLOW = 1, CTL_ROUNDS = 2, CTL_PROBES = 3, CTL_TRIGG
        // (not reset per pass: summed over the attempt) unit records the replay kernel found UNWRITTEN -- every unit is
        // taken by exactly one lane and leaves a record, so this stays 0; the records are filled with ones before the
        // automaton runs so that a unit nobody scanned could not pass for a result (its read goes to the group kernel)
+       // the lean reverse pass (rev_scan_kernel, brx_correct.hip): reads handed back to the group kernel, this pass / summed
+       CTL_REV_HANDBACK = 13, CTL_REV_HANDBACK_SUM = 14,
        CTL_LANE_UNWRITTEN = 15,
-       CTL_N = 16 };
+       // ... and the triggers it left to the verify pass (this pass / summed)
+       CTL_REV_TRIGS = 16, CTL_REV_TRIGS_SUM = 17,
+       CTL_N = 20 };
+
+// A trigger of a reverse pass that the lean scan could not settle itself (alt_nucs named exactly one alternative): the scan
+// goes on as if the method returned None, and the group kernel checks that it does (SRC == 2 of correct_kernel).
+struct TrigRec {
+    uint32_t r;    // read
+    uint32_t i;    // position of the trigger (the base that made the k-mer non-solid)
+    uint32_t elen; // error_len's result (Graph / GapSize; the rest of the read when it ran off the end)
+    uint32_t pad;
+    uint64_t fc;   // first_correct_kmer
+};
 
 struct PassParams {
     const uint32_t *bits;
@@ -45,6 +59,12 @@ struct PassParams {
     // list mode (one_kernel<G, K, true>): the kernel takes reads only[0 .. *only_n) instead of 0 .. n_reads
     const uint32_t *only = nullptr;
     const unsigned long long *only_n = nullptr;
+    // verify mode (correct_kernel<G, M, 2>): the work items are the triggers trig[0 .. min(*only_n, trig_cap)); a read
+    // whose trigger does NOT end in None is entered once into redo_list (count at ctrl[CTL_REV_HANDBACK], redo_flag dedupes)
+    const TrigRec *trig = nullptr;
+    uint32_t trig_cap = 0;
+    uint32_t *redo_list = nullptr;
+    uint32_t *redo_flag = nullptr;
 };
 
 __host__ __device__ __forceinline__ uint64_t slot_of(uint64_t o, uint64_t r, uint32_t slack)

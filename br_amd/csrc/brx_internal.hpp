@@ -159,6 +159,12 @@ struct brx_chain {
     uint64_t *d_scan_tmp;
     uint64_t scan_tmp_cap;
     uint64_t *d_path;   // graph-walk visited lists (Graph / GapSize)
+    uint32_t *d_rev_list = nullptr; // reads the lean reverse pass handed back (rev_scan_kernel)
+    uint64_t rev_list_bytes = 0;
+    uint32_t *d_rev_flag = nullptr; // ... one word per read: entered into that list already
+    uint64_t rev_flag_bytes = 0;
+    void *d_rev_trig = nullptr;     // triggers the lean reverse pass left to the verify pass (TrigRec)
+    uint64_t rev_trig_bytes = 0;
     uint64_t path_bytes;
     uint64_t *d_ctrl;   // device control block (work counter, overflow, stats)
     uint64_t *h_ctrl;   // pinned mirror

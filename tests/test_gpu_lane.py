@@ -287,3 +287,45 @@ def test_reverse_passes_in_lane_form(raw_reads, solid_fixture_bytes, lane_env, m
         monkeypatch.setenv("BRX_LANE_REV", "0")
         assert br_amd.Chain(gs2, [(m, 5, 7) for m in names], two_side=False).correct_reads(sreads) == got
         monkeypatch.setenv("BRX_LANE_REV", rev)
+
+
+@pytest.mark.parametrize("lean", ["", "0"])
+def test_lean_reverse_passes(raw_reads, solid_fixture_bytes, monkeypatch, lean):
+    """The reverse passes of Two / Graph / Greedy / GapSize in lean form (rev_scan_kernel: scan, error_len and alt_nucs
+    only; every read that would do anything else is handed back to the group kernel) against the oracle and against the
+    64-lane group kernel (BRX_REV_LEAN=0).  Fixture reads at k = 11 -- a dense set, so the reversed reads meet solid
+    k-mers and most reads are handed back -- and synthetic reads at k = 19 of which every third is stored back to front,
+    so that the REVERSE pass is the one that finds them correctable; reads of length 0, < k, k, k + 1; chains, so the
+    pass sees staged input that earlier passes have changed."""
+    if lean:
+        monkeypatch.setenv("BRX_REV_LEAN", lean)
+    else:
+        monkeypatch.delenv("BRX_REV_LEAN", raising=False)
+    monkeypatch.delenv("BRX_GROUP_REV", raising=False)
+    monkeypatch.delenv("BRX_GROUP", raising=False)
+    gs = br_amd.Pcon.from_pcon_solid(solid_fixture_bytes)
+    ref = O.Solid.from_bytes(solid_fixture_bytes)
+    reads = raw_reads[:30] + [b"", b"ACGTACGTAC", raw_reads[41][:11], raw_reads[42][:12], raw_reads[43][:27]]
+    for names in (["two"], ["graph"], ["greedy"], ["gap_size"], ["one", "two", "gap_size", "graph", "greedy"]):
+        chain = br_amd.Chain(gs, [(m, 5, 7) for m in names], two_side=False)
+        got = chain.correct_reads(reads)
+        om = O.build_methods(ref, names, 5, 7)
+        bad = [i for i, r in enumerate(reads) if got[i] != O.correct_record(om, r, False)]
+        assert not bad, (names, bad[:5])
+    k = 19
+    cfg = synth.config(genome_len=50_000, read_len=3_000)
+    g = synth.genome_host(cfg)
+    bases, offs = synth.reads_host(cfg, g, 0, 300)
+    sreads = [bases[int(offs[i]):int(offs[i + 1])].tobytes() for i in range(300)]
+    gs2 = br_amd.Pcon.from_count(sreads, k, 2)
+    ref2 = O.Solid.sparse_from_count(k, sreads, 2)
+    mixed = [r[::-1] if i % 3 == 0 else r for i, r in enumerate(sreads)] + [sreads[0][:k], sreads[1][:k + 1][::-1], sreads[2][:k - 1]]
+    for names, c in ((["two"], 2), (["graph"], 5), (["greedy"], 3), (["gap_size"], 5), (["gap_size", "graph", "two"], 4)):
+        chain = br_amd.Chain(gs2, [(m, c, 7) for m in names], two_side=False)
+        got = chain.correct_reads(mixed)
+        om = O.build_methods(ref2, names, c, 7)
+        want = [O.correct_record(om, r, False) for r in mixed]
+        bad = [i for i, r in enumerate(mixed) if got[i] != want[i]]
+        assert not bad, (names, bad[:5])
+        # the reversed reads were corrected by the reverse pass (the test would prove little otherwise)
+        assert any(want[i] != mixed[i] for i in range(0, 300, 3)), names

@@ -109,6 +109,7 @@ def report_mismatch(desc, case, seed, gs, ref, names, c, ms, two_side, reads, go
         rep["reruns"]["lane_off"] = differing(run_chain(gs, names, c, ms, two_side, reads, {"BRX_LANE": "0"}))
         rep["reruns"]["lane_mask_off"] = differing(run_chain(gs, names, c, ms, two_side, reads, {"BRX_LANE_MASK": "0"}))
         rep["reruns"]["lane_walk_off"] = differing(run_chain(gs, names, c, ms, two_side, reads, {"BRX_LANE_WALK": "0"}))
+        rep["reruns"]["rev_lean_off"] = differing(run_chain(gs, names, c, ms, two_side, reads, {"BRX_REV_LEAN": "0"}))
         gs2 = rebuild()
         rep["reruns"]["fresh_set_popcount"] = [int(gs2.popcount()), int(ref.popcount())]
         rep["reruns"]["same_settings_fresh_set"] = differing(run_chain(gs2, names, c, ms, two_side, reads))
@@ -174,6 +175,10 @@ while time.time() < t_end:
     env["BRX_LANE_REV"] = str(xrng.choice(["", "1", "2", "3", "3", "0"]))
     # graded chunk lengths at the end of a batch (One's lane form): on (default) / off
     env["BRX_LANE_TAIL"] = str(xrng.choice(["", "1", "1"]))
+    # reverse passes of Two / Graph / Greedy / GapSize in lean form (rev_scan_kernel): on (default) / off; the form exists
+    # for 64-lane reverse groups, which half of the cases now get whatever BRX_GROUP says
+    env["BRX_REV_LEAN"] = str(xrng.choice(["", "", "", "0"]))
+    rev64 = bool(xrng.random() < 0.5)
     if focus == "walklane":
         names[-1] = str(frng.choice(["graph", "gap_size"]))
         env.update({"BRX_LANE": "", "BRX_LANE_WALK": "", "BRX_LANE_CHUNK": str(frng.choice(["64", "100"])),
@@ -185,7 +190,7 @@ while time.time() < t_end:
             os.environ.pop(key, None)
         else:
             os.environ[key] = v
-    os.environ["BRX_GROUP_REV"] = os.environ.get("BRX_GROUP", "") or "64"
+    os.environ["BRX_GROUP_REV"] = "64" if rev64 else (os.environ.get("BRX_GROUP", "") or "64")
     strategy = _lib.COUNT_SORTED if (k >= 17 or (k >= 7 and rng.random() < 0.7)) else _lib.COUNT_DENSE
     if k > 21:
         continue_presence = True  # counting stops at k = 21: larger k are presence-only (large-kmer) sets
