@@ -533,24 +533,24 @@ __global__ __launch_bounds__(256, (M == BRX_ONE ? (G == 64 ? 7 : 6)
     while (__any(have)) {
         if (G == 64) {
             // trigger-free rounds of the 64-lane form (every method's reverse pass is almost only these) in a loop of
-            // their own, as in one_kernel: 64 positions, one probe each, ballot, accept; a round with a trigger or an
-            // overflowed index line is left to the general code below, which redoes its (pure) probes
+            // their own, as in one_kernel: 64 positions, one probe each, ballot, accept; a round with a trigger is
+            // left to the general code below, which redoes its (pure) probes
             while (have && st == ST_SCAN && !slow && n - i >= 65u && olen + 66u <= cap) {
                 const uint8_t c8 = ld(i + (uint32_t)lane);
                 const uint64_t km = lane_kmer64_dpp(kmer, (uint32_t)nuc2bit(c8), lane, mask);
-                bool s1 = false, u1 = false;
+                bool s1 = false;
                 if (HAS_ERRLEN && i + (uint32_t)lane < skip_until) {
                     // (known not solid: error_len asked about it behind the trigger that failed)
                 } else if (p.idx.lines) {
-                    const int pr = p.idx.line_bits ? index_probe_filtered(p.idx, km, k) : index_probe(p.idx, km, k);
-                    s1 = pr == 1;
-                    u1 = pr == 2;
+                    // (an overflowed index line is settled by the lane that met it, index_get: leaving the round to the
+                    // general code and its re-run cost two full rounds of the group, ten times per 10 kb read)
+                    s1 = index_get(p.idx, p.bits, km, k);
                 } else {
                     s1 = probe(p.bits, km, k);
                 }
                 const uint64_t bs = __ballot(s1);
                 const uint64_t trig = ~bs & ((bs << 1) | (prev ? 1ull : 0ull)); // mod.rs:73
-                if (__ballot(u1) | trig)
+                if (trig)
                     break;
                 out[olen + (uint32_t)lane] = c8; // mod.rs:100
                 olen += 64u;
@@ -565,20 +565,13 @@ __global__ __launch_bounds__(256, (M == BRX_ONE ? (G == 64 ? 7 : 6)
             // error_len (mod.rs:130-152) in a loop of its own, too: a trigger of a REVERSE pass is a chance hit, and error_len
             // then runs to the end of the read -- 64 k-mers a round, none of them solid -- through the general round's whole
             // state dispatch (Graph's reverse pass spent 5.6 G vector instructions where One's spends 2.6 G).  Full blocks
-            // without a solid k-mer stay here; the block that ends the search (a hit, the end of the read, an overflowed
-            // index line) is left to the general code, which redoes its (pure) probes.
+            // without a solid k-mer stay here; the block that ends the search (a hit, the end of the read) is left to the
+            // general code, which redoes its (pure) probes.
             while (HAS_ERRLEN && have && st == ST_ERRLEN && !slow && n - i > ej + 1u + 64u) {
                 const uint8_t c8 = ld(i + ej + 1u + (uint32_t)lane);
                 const uint64_t km = lane_kmer64_dpp(ek, (uint32_t)nuc2bit(c8), lane, mask);
-                bool s1, u1 = false;
-                if (p.idx.lines) {
-                    const int pr = p.idx.line_bits ? index_probe_filtered(p.idx, km, k) : index_probe(p.idx, km, k);
-                    s1 = pr == 1;
-                    u1 = pr == 2;
-                } else {
-                    s1 = probe(p.bits, km, k);
-                }
-                if (__ballot(s1 | u1))
+                const bool s1 = p.idx.lines ? index_get(p.idx, p.bits, km, k) : probe(p.bits, km, k);
+                if (__ballot(s1))
                     break;
                 ek = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(km >> 32), 63) << 32) |
                      (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)km, 63);
@@ -1605,23 +1598,17 @@ __global__ __launch_bounds__(256, (G == 64 ? BRX_ONE64_WAVES : 7)) void one_kern
             // One group per wave: everything below is wave-uniform.  The reverse pass of run_correction (src/lib.rs:48-55)
             // reads the bases back to front WITHOUT complementing them, so hardly any of its k-mers is solid and nearly
             // every round is "64 positions, no trigger": that round in a loop of its own, without the state dispatch,
-            // the trigger machinery and the register copies at their joins.  A round that does find a trigger (or an
-            // overflowed index line) is left to the general code below, which redoes its probes (they are pure).
+            // the trigger machinery and the register copies at their joins.  A round that does find a trigger is left to the general
+            // code below, which redoes its probes (they are pure).
             while (have && st == ST_SCAN && !slow && n - i >= 65u && olen + 66u <= cap) {
                 const uint8_t c8 = ld(i + (uint32_t)lane);
                 uint32_t sc;
                 const uint64_t km = lane_kmer(kmer, (uint32_t)nuc2bit(c8), sc);
-                bool s1, u1 = false;
-                if (p.idx.lines) {
-                    const int pr = p.idx.line_bits ? index_probe_filtered(p.idx, km, k) : index_probe(p.idx, km, k);
-                    s1 = pr == 1;
-                    u1 = pr == 2;
-                } else {
-                    s1 = probe(p.bits, km, k);
-                }
+                // (an overflowed index line is settled by the lane that met it, index_get)
+                const bool s1 = p.idx.lines ? index_get(p.idx, p.bits, km, k) : probe(p.bits, km, k);
                 const uint64_t bs = __ballot(s1);
                 const uint64_t trig = ~bs & ((bs << 1) | (prev ? 1ull : 0ull)); // mod.rs:73
-                if (__ballot(u1) | trig)
+                if (trig)
                     break;
                 out[olen + (uint32_t)lane] = c8; // mod.rs:100
                 olen += 64u;
@@ -2064,7 +2051,7 @@ __global__ __launch_bounds__(256, (G == 64 ? BRX_ONE64_WAVES : 7)) void one_kern
 // dispatch around rounds that are nearly all "64 positions, nothing".
 // ======================================================================================================================
 #ifndef BRX_REV_WAVES
-#define BRX_REV_WAVES 8
+#define BRX_REV_WAVES 7 // (8 / 7 / 6 waves measure the same; at 8 = 64 registers the notes spill)
 #endif
 template <int KT, int M>
 __global__ __launch_bounds__(256, BRX_REV_WAVES) void rev_scan_kernel(const PassParams pp, uint32_t *__restrict__ handback, uint32_t *__restrict__ redo_flag,
@@ -2091,19 +2078,7 @@ __global__ __launch_bounds__(256, BRX_REV_WAVES) void rev_scan_kernel(const Pass
     // KmerSet::get.  An index line that overflowed at build time cannot say "absent" (one probe in a thousand, i.e. nearly
     // every 10 kb read meets one): the lane asks the bit vector, or -- sparse sets, whose keys chain into the following
     // lines -- the next lines of the chain, while its wave waits.
-    const uint32_t n_lines_m1 = idx.lines ? (0xffffffffu >> idx.line_shift) : 0u;
-    auto ask = [&](uint64_t km) -> bool {
-        if (!idx.lines)
-            return probe(bits, km, k);
-        int a = idx.line_bits ? index_probe_filtered(idx, km, k) : index_probe(idx, km, k);
-        if (a == 2) {
-            if (bits)
-                return probe(bits, km, k);
-            for (uint32_t hop = 1; a == 2 && hop <= n_lines_m1; hop++)
-                a = index_probe(idx, km, k, hop);
-        }
-        return a == 1;
-    };
+    auto ask = [&](uint64_t km) -> bool { return idx.lines ? index_get(idx, bits, km, k) : probe(bits, km, k); };
     auto last_of = [&](uint64_t km, uint32_t l) -> uint64_t {
         return ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(km >> 32), (int)l) << 32) |
                (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)km, (int)l);

@@ -199,6 +199,28 @@ __device__ __forceinline__ int index_probe_filtered(const IdxView &v, uint64_t f
         return 0;
     return index_probe_at(v, key, home, 0u);
 }
+// KmerSet::get through the probe index with "cannot say" settled on the spot: the lane asks the bit vector when there is
+// one, else -- sets without one chain their overflowed keys into the following lines -- the next lines of the chain.
+// One probe in a thousand at configs[1]'s occupancy; the other lanes of the wave wait for it.
+__device__ __forceinline__ bool index_get(const IdxView &v, const uint32_t *__restrict__ bits, uint64_t fwd, int k)
+{
+    uint64_t key;
+    const uint32_t home = index_locate(v, fwd, k, key);
+    if (v.line_bits && !((v.line_bits[home >> 5] >> (home & 31u)) & 1u))
+        return false;
+    int a = index_probe_at(v, key, home, 0u);
+    if (a == 2) {
+        if (bits) {
+            const uint64_t h = khash(fwd, k);
+            return (bits[h >> 5] >> (h & 31u)) & 1u;
+        }
+        const uint32_t last = 0xffffffffu >> v.line_shift;
+        for (uint32_t hop = 1; a == 2 && hop <= last; hop++)
+            a = index_probe_at(v, key, home, hop);
+    }
+    return a == 1;
+}
+
 // find-or-insert of one k-mer into a chained table (sparse sets filled k-mer by k-mer, `br large-kmer`): true if the
 // key was not there.  Threads race for the first empty slot of a line with a CAS; slots never empty again, so
 // all threads see the same first empty slot and a key cannot land twice.
