@@ -2429,6 +2429,13 @@ int launch_one_list(const PassParams &p, hipStream_t s)
 
 namespace {
 
+// lanes per open trigger of the verify pass (BRX_REV_VERIFY_G = 4 / 8)
+int verify_group()
+{
+    const char *e = getenv("BRX_REV_VERIFY_G"); // (read on every use: the fuzzers sweep it)
+    return e && atoi(e) == 4 ? 4 : 8;
+}
+
 template <int M>
 int launch_method(const PassParams &p, int G, uint32_t blocks, size_t lds, hipStream_t s)
 {
@@ -2450,8 +2457,11 @@ int launch_method(const PassParams &p, int G, uint32_t blocks, size_t lds, hipSt
     }
     if constexpr (M == BRX_GRAPH || M == BRX_GAP_SIZE) {
         if (p.trig) {
-            // the triggers a lean reverse pass left open, one 8-lane group each (a walk step is four probes)
-            correct_kernel<8, M, 2><<<blocks, 256, lds, s>>>(p);
+            // the triggers a lean reverse pass left open, one narrow group each (a walk step is four probes)
+            if (verify_group() == 4)
+                correct_kernel<4, M, 2><<<blocks, 256, lds, s>>>(p);
+            else
+                correct_kernel<8, M, 2><<<blocks, 256, lds, s>>>(p);
             return BRX_OK;
         }
         if (p.only) {
@@ -2518,7 +2528,7 @@ int launch_pass(PassParams p, const brx_method_t &md, int G, hipStream_t s)
         // a list is a few reads and the grid loops over it (the open triggers are many: as many groups as the visited lists
         // the chain has sized allow); stay inside those lists (see launch_walk_list)
         const uint64_t sized_groups = (uint64_t)pass_blocks(p.n_reads, walk_group()) * (256u / (uint32_t)walk_group());
-        const uint32_t per_block = p.trig ? 32u : 4u; // (8-lane groups for the triggers, 64-lane groups for the reads)
+        const uint32_t per_block = p.trig ? 256u / (uint32_t)verify_group() : 4u; // (narrow groups for the triggers, 64-lane groups for the reads)
         blocks = (uint32_t)(sized_groups / per_block);
         blocks = blocks < 1u ? 1u : (blocks > MAX_BLOCKS ? MAX_BLOCKS : blocks);
     }

@@ -179,6 +179,7 @@ while time.time() < t_end:
     # for 64-lane reverse groups, which half of the cases now get whatever BRX_GROUP says
     env["BRX_REV_LEAN"] = str(xrng.choice(["", "", "", "0"]))
     rev64 = bool(xrng.random() < 0.5)
+    env["BRX_REV_VERIFY_G"] = str(xrng.choice(["", "4"]))  # lanes per open trigger of the verify pass
     if focus == "walklane":
         names[-1] = str(frng.choice(["graph", "gap_size"]))
         env.update({"BRX_LANE": "", "BRX_LANE_WALK": "", "BRX_LANE_CHUNK": str(frng.choice(["64", "100"])),
