@@ -5,7 +5,8 @@
 // unmaps it), hipMalloc pays for the page tables again -- measured with tools/e2e_repeat.py: one repetition in eight lost
 // 0.7 s to two frees, and bench.py's `e2e` block showed build legs of 1.4 s instead of 0.13 s.  Every hipMalloc / hipFree
 // of the library's translation units goes through dev_alloc / dev_free (the macros at the end of brx_internal.hpp);
-// blocks of at least POOL_MIN bytes are parked here when freed, up to BRX_DEVPOOL_GB (default 48) GiB per process, and a
+// blocks of at least POOL_MIN bytes are parked here when freed, up to BRX_DEVPOOL_GB (default 48) GiB per process and only
+// while at least an eighth of the card is free, and a
 // request takes the smallest parked block that is large enough and at most twice its size.
 //
 // Same contract as the runtime's: a freed block may still be in use by queued kernels (hipFree waits for the device), so
@@ -72,6 +73,8 @@ void drop_all_locked(std::vector<void *> &out)
     g_parked_bytes = 0;
 }
 } // namespace
+
+void dev_pool_trim();
 
 hipError_t dev_alloc(void **out, size_t bytes)
 {
@@ -150,6 +153,17 @@ hipError_t dev_free(void *p)
         (void)hipSetDevice(cur);
     if (se != hipSuccess)
         return hipFree(p);
+    // The pool's memory is invisible to every other allocator on the card (torch's, RCCL's, another rank's pool when
+    // several processes share a device): when the card runs short -- less than an eighth of it free -- nothing is parked
+    // and what is parked goes back to the runtime.
+    {
+        size_t fr = 0, tot = 0;
+        if (hipMemGetInfo(&fr, &tot) == hipSuccess && tot != 0 && fr < tot / 8) {
+            dev_pool_trim();
+            return hipFree(p);
+        }
+        (void)hipGetLastError();
+    }
     std::vector<void *> drop;
     {
         std::lock_guard<std::mutex> g(g_mu);
