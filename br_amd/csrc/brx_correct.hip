@@ -2344,6 +2344,10 @@ int group_width(bool reverse_pass = false, bool indexed = false, uint32_t n_read
 }
 
 constexpr uint32_t MAX_BLOCKS = 256u * 8u;
+// Visited lists a chain always has, however few reads its batch holds: one block of the narrowest kernel that indexes them
+// by its global group number (4-lane groups: 64 a block).  The list and verify launches size their grids from the lists
+// the chain has (sized_path_lists), never from a width of their own.
+constexpr uint32_t MIN_PATH_LISTS = 64u;
 
 // lanes per read of Graph's and GapSize's forward passes (BRX_GROUP_WALK = 4 / 8 / 16)
 int walk_group()
@@ -2383,6 +2387,13 @@ uint32_t pass_blocks(uint32_t n_reads, int G, bool balanced = false)
     return (uint32_t)want;
 }
 
+// visited lists of a chain for a batch of n_reads (the walking methods' group kernels index them by global group number)
+uint64_t sized_path_lists(uint32_t n_reads)
+{
+    const uint64_t g = (uint64_t)pass_blocks(n_reads, walk_group()) * (256u / (uint32_t)walk_group());
+    return g < MIN_PATH_LISTS ? MIN_PATH_LISTS : g;
+}
+
 template <int G>
 void launch_one(const PassParams &p, uint32_t blocks, hipStream_t s)
 {
@@ -2401,8 +2412,8 @@ namespace brx {
 // are sized for pass_blocks(n_reads, walk_group()) blocks of groups at least as wide, so the grid stays inside them)
 int launch_walk_list(const PassParams &p, int method, hipStream_t s)
 {
-    const uint64_t sized_groups = (uint64_t)pass_blocks(p.n_reads, walk_group()) * (256u / (uint32_t)walk_group());
-    uint32_t bl = (uint32_t)(sized_groups / 32u); // 32 eight-lane groups per block (the chain sizes at least 32 lists)
+    const uint64_t sized_groups = sized_path_lists(p.n_reads);
+    uint32_t bl = (uint32_t)(sized_groups / 32u); // 32 eight-lane groups per block (the chain sizes at least 64 lists)
     bl = bl < 1u ? 1u : (bl > 128u ? 128u : bl);
     if (method == BRX_GRAPH)
         correct_kernel<8, BRX_GRAPH, 1><<<bl, 256, 0, s>>>(p);
@@ -2527,7 +2538,7 @@ int launch_pass(PassParams p, const brx_method_t &md, int G, hipStream_t s)
     if (p.only || p.trig) {
         // a list is a few reads and the grid loops over it (the open triggers are many: as many groups as the visited lists
         // the chain has sized allow); stay inside those lists (see launch_walk_list)
-        const uint64_t sized_groups = (uint64_t)pass_blocks(p.n_reads, walk_group()) * (256u / (uint32_t)walk_group());
+        const uint64_t sized_groups = sized_path_lists(p.n_reads);
         const uint32_t per_block = p.trig ? 256u / (uint32_t)verify_group() : 4u; // (narrow groups for the triggers, 64-lane groups for the reads)
         blocks = (uint32_t)(sized_groups / per_block);
         blocks = blocks < 1u ? 1u : (blocks > MAX_BLOCKS ? MAX_BLOCKS : blocks);
@@ -2841,9 +2852,7 @@ static int correct_batch_device_locked(brx_chain_t *ch, const uint8_t *d_bases, 
             // one visited list per group that can be resident: walking methods run 16-lane groups or wider, so a grid of
             // pass_blocks(n_reads, 16) blocks of 16 groups bounds every width (a handful of redone reads needs a
             // handful of lists, not 32768 of them)
-            uint64_t n_groups = (uint64_t)pass_blocks(n_reads, walk_group()) * (256u / (uint32_t)walk_group());
-            if (n_groups < 32u)
-                n_groups = 32u; // (one block of the list kernel, launch_walk_list)
+            const uint64_t n_groups = sized_path_lists(n_reads); // (at least one block of the narrowest list / verify kernel)
             BRX_TRY(ensure((void **)&ch->d_path, &ch->path_bytes, n_groups * maxpath * 8ull));
         }
         const uint64_t stage_need = total_bases + (total_bases >> 2) * slack + 64ull * ((uint64_t)n_reads + 1) + 64;

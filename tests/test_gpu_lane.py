@@ -329,3 +329,28 @@ def test_lean_reverse_passes(raw_reads, solid_fixture_bytes, monkeypatch, lean):
         assert not bad, (names, bad[:5])
         # the reversed reads were corrected by the reverse pass (the test would prove little otherwise)
         assert any(want[i] != mixed[i] for i in range(0, 300, 3)), names
+
+
+@pytest.mark.parametrize("walk_group", ["", "16"])
+def test_verify_groups_stay_inside_the_visited_lists_of_a_small_batch(raw_reads, solid_fixture_bytes, monkeypatch, walk_group):
+    """Fuzz seed 211 case 5889 / seed 7 case 226 (round 4): a batch of a few reads has the chain's minimum of visited
+    lists, and the verify pass of the lean reverse form, launched with 4-lane groups (64 a block), indexed 64 lists where
+    the chain had sized 32 -- with three-entry lists (BRX_MAXPATH=3) the groups overwrote each other's walks and reads
+    came out wrong.  The grid is now cut from the lists the chain has (sized_path_lists, at least 64)."""
+    monkeypatch.setenv("BRX_REV_VERIFY_G", "4")
+    monkeypatch.setenv("BRX_MAXPATH", "3")
+    monkeypatch.delenv("BRX_REV_LEAN", raising=False)
+    monkeypatch.delenv("BRX_GROUP_REV", raising=False)
+    monkeypatch.delenv("BRX_GROUP", raising=False)
+    if walk_group:
+        monkeypatch.setenv("BRX_GROUP_WALK", walk_group)
+    else:
+        monkeypatch.delenv("BRX_GROUP_WALK", raising=False)
+    gs = br_amd.Pcon.from_pcon_solid(solid_fixture_bytes)
+    ref = O.Solid.from_bytes(solid_fixture_bytes)
+    reads = [r[:300] for r in raw_reads[:18]] + [raw_reads[18][:94], raw_reads[19][:1700]]
+    for names, c in ((["gap_size", "graph", "graph"], 0), (["graph", "gap_size", "two"], 5)):
+        got = br_amd.Chain(gs, [(m, c, 1) for m in names], two_side=False).correct_reads(reads)
+        om = O.build_methods(ref, names, c, 1)
+        bad = [i for i, r in enumerate(reads) if got[i] != O.correct_record(om, r, False)]
+        assert not bad, (names, bad[:5])
