@@ -2078,8 +2078,10 @@ __global__ __launch_bounds__(256, BRX_REV_WAVES) void rev_scan_kernel(const Pass
     // KmerSet::get.  An index line that overflowed at build time cannot say "absent" (one probe in a thousand, i.e. nearly
     // every 10 kb read meets one): the lane asks the bit vector, or -- sparse sets, whose keys chain into the following
     // lines -- the next lines of the chain, while its wave waits.
-    auto ask = [&](uint64_t km) -> bool { return idx.lines ? index_get(idx, bits, km, k) : probe(bits, km, k); };
-    auto last_of = [&](uint64_t km, uint32_t l) -> uint64_t {
+    // (always_inline: left to itself the compiler CALLS the probe from the three places that ask -- s_swappc, registers saved
+    // through lanes and scratch -- and the scan ran at 9.1 ms per Gbp where one_kernel<64>'s identical loop takes 5.7)
+    auto ask = [&](uint64_t km) __attribute__((always_inline)) -> bool { return idx.lines ? index_get(idx, bits, km, k) : probe(bits, km, k); };
+    auto last_of = [&](uint64_t km, uint32_t l) __attribute__((always_inline)) -> uint64_t {
         return ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(km >> 32), (int)l) << 32) |
                (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)km, (int)l);
     };
@@ -2111,7 +2113,7 @@ __global__ __launch_bounds__(256, BRX_REV_WAVES) void rev_scan_kernel(const Pass
         const uint64_t s0 = slot_of(o0, r, slack), s1 = slot_of(o1, (uint64_t)r + 1, slack);
         uint8_t *out = out_base + s0;
         const uint32_t cap = (uint32_t)(s1 - s0);
-        auto ld = [&](uint32_t j) -> uint8_t { return in[flip ? (n - 1u - j) : j]; };
+        auto ld = [&](uint32_t j) __attribute__((always_inline)) -> uint8_t { return in[flip ? (n - 1u - j) : j]; };
 
         if (n < (uint32_t)k) { // mod.rs:56-58
             for (uint32_t j = (uint32_t)lane; j < n; j += 64u)
@@ -2450,6 +2452,14 @@ int verify_group()
 template <int M>
 int launch_method(const PassParams &p, int G, uint32_t blocks, size_t lds, hipStream_t s)
 {
+    if constexpr (M == BRX_ONE) {
+        if (p.trig) { // the triggers One's lean reverse pass left open (BRX_REV_LEAN_ONE), one 8-lane group each
+            correct_kernel<8, BRX_ONE, 2><<<blocks, 256, lds, s>>>(p);
+            return BRX_OK;
+        }
+        if (p.only)
+            return launch_one_list(p, s);
+    }
     if (M == BRX_ONE && G != 32) {
         // (4-lane groups exist in this form only)
         // BRX_ONE_V1=1: the first form of the kernel (A/B runs; results are identical)
@@ -2594,6 +2604,7 @@ int launch_rev_lean(brx_chain *ch, PassParams p, const brx_method_t &md, hipStre
         const uint32_t blocks = pass_blocks(p.n_reads, 64);
         KernelTimer t(names[md.method], s);
         switch (md.method) {
+        case BRX_ONE: launch_rev_scan<BRX_ONE>(p, ch->d_rev_list, ch->d_rev_flag, trig, trig_cap, blocks, s); break;
         case BRX_GRAPH: launch_rev_scan<BRX_GRAPH>(p, ch->d_rev_list, ch->d_rev_flag, trig, trig_cap, blocks, s); break;
         case BRX_GAP_SIZE: launch_rev_scan<BRX_GAP_SIZE>(p, ch->d_rev_list, ch->d_rev_flag, trig, trig_cap, blocks, s); break;
         default: set_error("launch_rev_lean: method %u", md.method); return BRX_ERR_ARG;
@@ -2951,7 +2962,10 @@ static int correct_batch_device_locked(brx_chain_t *ch, const uint8_t *d_bases, 
                 }
                 // (Two's and Greedy's reverse passes cost 4 ms per Gbp of their 55 / 69 in the group kernel: the lean form
                 // was measured for them, too, and bought nothing -- profiles/r4o_rev_lean_ab.txt)
-                const bool lean = dir == 1 && (mth == BRX_GRAPH || mth == BRX_GAP_SIZE) && gw == 64 && rev_lean_on();
+                // One's reverse pass in the same form: BRX_REV_LEAN_ONE=1 (measured: profiles/r4o_rev_lean_ab.txt)
+                const char *e_lo = getenv("BRX_REV_LEAN_ONE");
+                const bool lean_one = mth == BRX_ONE && e_lo && *e_lo == '1';
+                const bool lean = dir == 1 && (mth == BRX_GRAPH || mth == BRX_GAP_SIZE || lean_one) && gw == 64 && rev_lean_on();
                 if (lean)
                     BRX_TRY(launch_rev_lean(ch, p, ch->methods[m], s));
                 else

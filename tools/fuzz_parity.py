@@ -180,6 +180,7 @@ while time.time() < t_end:
     env["BRX_REV_LEAN"] = str(xrng.choice(["", "", "", "0"]))
     rev64 = bool(xrng.random() < 0.5)
     env["BRX_REV_VERIFY_G"] = str(xrng.choice(["", "4"]))  # lanes per open trigger of the verify pass
+    env["BRX_REV_LEAN_ONE"] = str(xrng.choice(["", "1"]))  # One's reverse pass in the lean form, too
     if focus == "walklane":
         names[-1] = str(frng.choice(["graph", "gap_size"]))
         env.update({"BRX_LANE": "", "BRX_LANE_WALK": "", "BRX_LANE_CHUNK": str(frng.choice(["64", "100"])),
