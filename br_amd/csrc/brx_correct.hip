@@ -2042,16 +2042,16 @@ __global__ __launch_bounds__(256, (G == 64 ? BRX_ONE64_WAVES : 7)) void one_kern
 //                                                          reversed read; the scenarios' look-aheads do not hold
 // i.e. the read leaves the pass as it came.  This kernel scans on that assumption -- scan, error_len, alt_nucs, one wave
 // per read, 64 k-mers a round, nothing of the methods' state -- and NOTES every trigger of the third kind (TrigRec).  A
-// second launch, correct_kernel<8 or 16, M, 2>, takes the notes as its work items: a narrow group enters the method at
+// second launch, correct_kernel<8, M, 2> (<4, M, 2> on request), takes the notes as its work items: a narrow group enters the method at
 // alt_nucs with the state the scan would have had there, runs it, writes nothing, and flags the read unless the result
-// is None; flagged reads (336 of 100 000 in One's reverse pass over the bench's data) are then corrected from scratch by
-// the list form of the group kernel.  A read none of whose triggers is flagged is exactly the copy the reference makes:
+// is None; flagged reads (none for Graph, 4 956 of 100 000 for GapSize over the bench's data) are then corrected from
+// scratch by the 64-lane group kernel over their list (correct_kernel<64, M, 1>).  A read none of whose triggers is flagged is exactly the copy the reference makes:
 // by induction over its triggers, each was reached with the reference's state and returned None like the reference's.
-// What it saves is the group kernel's register file (5 waves per SIMD against 8 here) and the instructions of its state
+// What it saves is the group kernel's register file (5 waves per SIMD against 7 here) and the instructions of its state
 // dispatch around rounds that are nearly all "64 positions, nothing".
 // ======================================================================================================================
 #ifndef BRX_REV_WAVES
-#define BRX_REV_WAVES 7 // (8 / 7 / 6 waves measure the same; at 8 = 64 registers the notes spill)
+#define BRX_REV_WAVES 7 // (8 / 7 / 6 waves measure the same: profiles/r4o_rev_lean_ab.txt; 62 registers for k = 19 / 21)
 #endif
 template <int KT, int M>
 __global__ __launch_bounds__(256, BRX_REV_WAVES) void rev_scan_kernel(const PassParams pp, uint32_t *__restrict__ handback, uint32_t *__restrict__ redo_flag,
